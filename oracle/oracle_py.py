@@ -1,0 +1,632 @@
+"""ctypes binding of the CPU ORACLE (oracle/libvga_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Importers allowed: tests/, __graft_entry__.smoke(), bench.py's
+cpu_baseline leg.  Nothing under rs-vgaligner_amd/ may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvga_oracle.so")
+
+U64MAX = (1 << 64) - 1
+FORWARD, REVERSE = 0, 1
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+class SeqPos(C.Structure):
+    _fields_ = [("orient", C.c_uint8), ("position", C.c_uint64)]
+
+    def t(self):
+        return (int(self.orient), int(self.position))
+
+
+class KmerPos(C.Structure):
+    _fields_ = [("start", SeqPos), ("end", SeqPos)]
+
+    def t(self):
+        return (self.start.t(), self.end.t())
+
+
+class NodeRef(C.Structure):
+    _fields_ = [("seq_idx", C.c_uint64), ("edge_idx", C.c_uint64), ("edges_to_node", C.c_uint64)]
+
+    def t(self):
+        return (int(self.seq_idx), int(self.edge_idx), int(self.edges_to_node))
+
+
+class GraphKmerView(C.Structure):
+    _fields_ = [
+        ("seq", C.c_void_p),
+        ("begin_offset", SeqPos),
+        ("end_offset", SeqPos),
+        ("first_handle", C.c_uint64),
+        ("last_handle", C.c_uint64),
+        ("handle_orient", C.c_int),
+        ("forks", C.c_uint64),
+    ]
+
+
+class Anchor(C.Structure):
+    _fields_ = [
+        ("id", C.c_uint64),
+        ("query_begin", C.c_uint64),
+        ("query_end", C.c_uint64),
+        ("target_begin", SeqPos),
+        ("target_end", SeqPos),
+        ("max_chain_score", C.c_double),
+        ("best_predecessor_id", C.c_int64),
+    ]
+
+
+class Chain(C.Structure):
+    _fields_ = [("anchors", C.POINTER(Anchor)), ("n", C.c_size_t), ("is_placeholder", C.c_int)]
+
+
+class ChainSet(C.Structure):
+    _fields_ = [("chains", C.POINTER(Chain)), ("n", C.c_size_t), ("curr_max", C.c_double)]
+
+
+class Range(C.Structure):
+    _fields_ = [("orient", C.c_int), ("handles", C.POINTER(C.c_uint64)), ("n", C.c_size_t)]
+
+
+class Subgraph(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_size_t),
+        ("seqs", C.POINTER(C.c_char_p)),
+        ("seq_lens", C.POINTER(C.c_size_t)),
+        ("n_edges", C.c_size_t),
+        ("edge_src", C.POINTER(C.c_size_t)),
+        ("edge_dst", C.POINTER(C.c_size_t)),
+    ]
+
+
+class PoaParams(C.Structure):
+    _fields_ = [
+        ("match", C.c_int32),
+        ("mismatch", C.c_int32),
+        ("gap_open1", C.c_int32),
+        ("gap_ext1", C.c_int32),
+        ("gap_open2", C.c_int32),
+        ("gap_ext2", C.c_int32),
+        ("wb", C.c_int32),
+        ("wf", C.c_double),
+    ]
+
+
+class PoaResult(C.Structure):
+    _fields_ = [
+        ("ok", C.c_int),
+        ("best_score", C.c_int32),
+        ("n_abpoa_nodes", C.c_size_t),
+        ("abpoa_nodes", C.POINTER(C.c_uint32)),
+        ("graph_nodes", C.POINTER(C.c_uint32)),
+        ("aln_start_offset", C.c_uint64),
+        ("aln_end_offset", C.c_uint64),
+        ("n_aligned_bases", C.c_uint64),
+        ("cigar", C.c_char_p),
+        ("cs_string", C.c_char_p),
+        ("n_rows", C.c_uint64),
+        ("n_cells", C.c_uint64),
+    ]
+
+
+class MapParams(C.Structure):
+    _fields_ = [
+        ("bandwidth", C.c_uint64),
+        ("max_gap", C.c_uint64),
+        ("chain_min_n_anchors", C.c_uint64),
+        ("align_best_n", C.c_uint64),
+        ("also_align", C.c_int),
+        ("poa", PoaParams),
+    ]
+
+
+class MapStats(C.Structure):
+    _fields_ = [
+        (n, C.c_uint64)
+        for n in (
+            "n_reads n_anchors n_hits n_chains n_placeholder_reads n_aligned_reads "
+            "poa_rows poa_cells cigar_ops path_bases"
+        ).split()
+    ] + [(n, C.c_double) for n in "t_anchor_s t_chain_s t_subgraph_s t_poa_s".split()]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
+    L.og_graph_new.restype = vp
+    L.og_graph_free.argtypes = [vp]
+    L.og_graph_add_node.argtypes = [vp, u64, C.c_char_p, sz]
+    L.og_graph_add_edge.argtypes = [vp, u64, u64]
+    L.og_graph_add_path.argtypes = [vp, C.c_char_p, C.POINTER(u64), sz]
+    L.og_graph_load_gfa.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.og_graph_n_nodes.argtypes = [vp]
+    L.og_graph_n_nodes.restype = sz
+    L.og_graph_n_paths.argtypes = [vp]
+    L.og_graph_n_paths.restype = sz
+    L.og_graph_path_name.argtypes = [vp, sz]
+    L.og_graph_path_name.restype = C.c_char_p
+    L.og_graph_path_len.argtypes = [vp, sz]
+    L.og_graph_path_len.restype = sz
+    L.og_graph_path_steps.argtypes = [vp, sz]
+    L.og_graph_path_steps.restype = C.POINTER(u64)
+    L.og_graph_node_len.argtypes = [vp, u64]
+    L.og_graph_node_len.restype = sz
+    L.og_graph_sequence.argtypes = [vp, u64, C.c_char_p]
+    L.og_graph_sequence.restype = sz
+    L.og_graph_neighbors.argtypes = [vp, u64, C.c_int, C.POINTER(u64), sz]
+    L.og_graph_neighbors.restype = sz
+
+    L.og_index_build.argtypes = [vp, u64, u64, u64, C.POINTER(vp)]
+    L.og_index_free.argtypes = [vp]
+    for name in ("k", "seq_length", "n_nodes", "n_edges", "n_kmers", "n_kmer_pos", "n_graph_kmers"):
+        f = getattr(L, "og_index_" + name)
+        f.argtypes = [vp]
+        f.restype = u64
+    L.og_index_seq_fwd.argtypes = [vp]
+    L.og_index_seq_fwd.restype = C.c_char_p
+    L.og_index_seq_rev.argtypes = [vp]
+    L.og_index_seq_rev.restype = C.c_char_p
+    L.og_index_seq_bv.argtypes = [vp]
+    L.og_index_seq_bv.restype = C.POINTER(C.c_uint8)
+    L.og_index_edges.argtypes = [vp]
+    L.og_index_edges.restype = C.POINTER(u64)
+    L.og_index_node_ref.argtypes = [vp]
+    L.og_index_node_ref.restype = C.POINTER(NodeRef)
+    L.og_index_kmer_keys.argtypes = [vp]
+    L.og_index_kmer_keys.restype = C.POINTER(C.c_char)
+    L.og_index_kmer_starts.argtypes = [vp]
+    L.og_index_kmer_starts.restype = C.POINTER(u64)
+    L.og_index_kmer_pos_table.argtypes = [vp]
+    L.og_index_kmer_pos_table.restype = C.POINTER(KmerPos)
+    L.og_index_graph_kmer.argtypes = [vp, u64, C.POINTER(GraphKmerView)]
+    L.og_generate_kmers_count.argtypes = [vp, u64, u64, u64]
+    L.og_generate_kmers_count.restype = C.c_int64
+    L.og_index_find_positions.argtypes = [vp, C.c_char_p, sz, C.POINTER(C.POINTER(KmerPos))]
+    L.og_index_find_positions.restype = sz
+    for name in ("bv_rank", "bv_inverse_rank", "bv_select"):
+        f = getattr(L, "og_index_" + name)
+        f.argtypes = [vp, u64]
+        f.restype = u64
+    L.og_index_node_id_from_seqpos.argtypes = [vp, SeqPos]
+    L.og_index_node_id_from_seqpos.restype = u64
+    L.og_index_handle_from_seqpos.argtypes = [vp, SeqPos]
+    L.og_index_handle_from_seqpos.restype = u64
+    L.og_index_seq_from_handle.argtypes = [vp, u64, C.c_char_p, sz]
+    L.og_index_seq_from_handle.restype = sz
+    for name in ("edges_from_handle", "incoming_edges", "outgoing_edges"):
+        f = getattr(L, "og_index_" + name)
+        f.argtypes = [vp, u64, C.POINTER(u64), sz]
+        f.restype = sz
+
+    L.og_anchors_for_query.argtypes = [vp, C.c_char_p, sz, C.c_int, C.POINTER(C.POINTER(Anchor))]
+    L.og_anchors_for_query.restype = sz
+    L.og_score_anchor.argtypes = [C.POINTER(Anchor), C.POINTER(Anchor), u64, u64]
+    L.og_score_anchor.restype = C.c_double
+    L.og_chain_anchors.argtypes = [C.POINTER(Anchor), sz, u64, u64, u64, u64, C.POINTER(ChainSet), C.POINTER(Anchor)]
+    L.og_chain_set_free.argtypes = [C.POINTER(ChainSet)]
+    L.og_range_free.argtypes = [C.POINTER(Range)]
+    L.og_find_range_chain.argtypes = [vp, C.POINTER(Chain), C.POINTER(Range)]
+    L.og_extend_range_chain_2.argtypes = [vp, C.POINTER(Chain), u64, C.POINTER(Range), C.POINTER(Range)]
+    L.og_subgraph_free.argtypes = [C.POINTER(Subgraph)]
+    L.og_find_nodes_edges_for_abpoa.argtypes = [vp, C.POINTER(Range), C.POINTER(Subgraph)]
+    L.og_poa_default_params.argtypes = [C.POINTER(PoaParams)]
+    L.og_poa_result_free.argtypes = [C.POINTER(PoaResult)]
+    L.og_poa_align.argtypes = [
+        C.POINTER(C.c_char_p), C.POINTER(sz), sz, C.POINTER(sz), C.POINTER(sz), sz,
+        C.c_char_p, sz, C.POINTER(PoaParams), C.POINTER(PoaResult),
+    ]
+    L.og_gaf_from_chain.argtypes = [vp, C.POINTER(Chain), C.c_char_p, u64]
+    L.og_gaf_from_chain.restype = vp
+    L.og_gaf_from_placeholder.argtypes = [C.c_char_p, u64]
+    L.og_gaf_from_placeholder.restype = vp
+    L.og_gaf_from_poa.argtypes = [C.POINTER(Range), C.POINTER(PoaResult), C.c_char_p, u64]
+    L.og_gaf_from_poa.restype = vp
+    L.og_map_default_params.argtypes = [C.POINTER(MapParams)]
+    L.og_map_reads.argtypes = [
+        vp, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), sz, C.POINTER(MapParams),
+        C.POINTER(vp), C.POINTER(vp), C.POINTER(MapStats),
+    ]
+    L.og_free.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def pack(node_id: int, rev: bool = False) -> int:
+    return (node_id << 1) | (1 if rev else 0)
+
+
+def _take_str(ptr) -> str:
+    s = C.string_at(ptr).decode()
+    lib().og_free(ptr)
+    return s
+
+
+class Graph:
+    """HashGraph stand-in."""
+
+    def __init__(self, handle=None):
+        self.L = lib()
+        self.h = handle if handle is not None else self.L.og_graph_new()
+
+    @classmethod
+    def from_gfa(cls, path: str) -> "Graph":
+        L = lib()
+        out = C.c_void_p()
+        rc = L.og_graph_load_gfa(path.encode(), C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"og_graph_load_gfa({path}) -> {rc}")
+        return cls(out)
+
+    @classmethod
+    def from_nodes_edges(cls, nodes: Sequence[Tuple[int, str]], edges: Sequence[Tuple[int, int]]) -> "Graph":
+        g = cls()
+        for nid, seq in nodes:
+            g.create_handle(seq, nid)
+        for a, b in edges:
+            g.create_edge(pack(a), pack(b))
+        return g
+
+    def create_handle(self, seq: str, node_id: int) -> int:
+        rc = self.L.og_graph_add_node(self.h, node_id, seq.encode(), len(seq))
+        if rc != 0:
+            raise RuntimeError(f"add_node -> {rc}")
+        return pack(node_id)
+
+    def create_edge(self, left: int, right: int) -> None:
+        rc = self.L.og_graph_add_edge(self.h, left, right)
+        if rc != 0:
+            raise RuntimeError(f"add_edge -> {rc}")
+
+    def n_nodes(self) -> int:
+        return self.L.og_graph_n_nodes(self.h)
+
+    def sequence(self, handle: int) -> str:
+        n = self.L.og_graph_node_len(self.h, handle >> 1)
+        buf = C.create_string_buffer(n + 1)
+        self.L.og_graph_sequence(self.h, handle, buf)
+        return buf.raw[:n].decode()
+
+    def neighbors(self, handle: int, left: bool) -> List[int]:
+        buf = (C.c_uint64 * 4096)()
+        n = self.L.og_graph_neighbors(self.h, handle, 1 if left else 0, buf, 4096)
+        return [int(buf[i]) for i in range(n)]
+
+    def paths(self) -> List[Tuple[str, List[int]]]:
+        out = []
+        for i in range(self.L.og_graph_n_paths(self.h)):
+            name = self.L.og_graph_path_name(self.h, i).decode()
+            n = self.L.og_graph_path_len(self.h, i)
+            steps = self.L.og_graph_path_steps(self.h, i)
+            out.append((name, [int(steps[j]) for j in range(n)]))
+        return out
+
+    def generate_kmers_count(self, k: int, edge_max: int = 100, degree_max: int = 100) -> int:
+        return int(self.L.og_generate_kmers_count(self.h, k, edge_max, degree_max))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.og_graph_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+@dataclass
+class AnchorT:
+    id: int
+    query_begin: int
+    query_end: int
+    target_begin: Tuple[int, int]
+    target_end: Tuple[int, int]
+    max_chain_score: float
+    best_predecessor_id: int
+
+
+def _anchor_t(a: Anchor) -> AnchorT:
+    return AnchorT(int(a.id), int(a.query_begin), int(a.query_end), a.target_begin.t(), a.target_end.t(),
+                   float(a.max_chain_score), int(a.best_predecessor_id))
+
+
+class Index:
+    def __init__(self, graph: Graph, k: int, max_furcations: int = 100, max_degree: int = 100):
+        self.L = lib()
+        self.graph = graph
+        out = C.c_void_p()
+        rc = self.L.og_index_build(graph.h, k, max_furcations, max_degree, C.byref(out))
+        if rc != 0:
+            raise RuntimeError(f"og_index_build -> {rc}")
+        self.h = out
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.og_index_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # --- scalar accessors
+    @property
+    def k(self): return int(self.L.og_index_k(self.h))
+    @property
+    def seq_length(self): return int(self.L.og_index_seq_length(self.h))
+    @property
+    def n_nodes(self): return int(self.L.og_index_n_nodes(self.h))
+    @property
+    def n_edges(self): return int(self.L.og_index_n_edges(self.h))
+    @property
+    def n_kmers(self): return int(self.L.og_index_n_kmers(self.h))
+    @property
+    def n_kmer_pos(self): return int(self.L.og_index_n_kmer_pos(self.h))
+    @property
+    def n_graph_kmers(self): return int(self.L.og_index_n_graph_kmers(self.h))
+    @property
+    def seq_fwd(self): return self.L.og_index_seq_fwd(self.h).decode()
+    @property
+    def seq_rev(self): return self.L.og_index_seq_rev(self.h).decode()
+
+    def seq_bv(self) -> List[int]:
+        p = self.L.og_index_seq_bv(self.h)
+        return [int(p[i]) for i in range(self.seq_length + 1)]
+
+    def node_ref(self) -> List[Tuple[int, int, int]]:
+        p = self.L.og_index_node_ref(self.h)
+        return [p[i].t() for i in range(self.n_nodes + 1)]
+
+    def edges(self) -> List[int]:
+        p = self.L.og_index_edges(self.h)
+        return [int(p[i]) for i in range(self.n_edges)]
+
+    def kmer_keys(self) -> List[str]:
+        k = self.k
+        raw = C.string_at(self.L.og_index_kmer_keys(self.h), self.n_kmers * k)
+        return [raw[i * k:(i + 1) * k].decode() for i in range(self.n_kmers)]
+
+    def kmer_starts(self) -> List[int]:
+        p = self.L.og_index_kmer_starts(self.h)
+        return [int(p[i]) for i in range(self.n_kmers)]
+
+    def kmer_pos_table(self):
+        p = self.L.og_index_kmer_pos_table(self.h)
+        return [p[i].t() for i in range(self.n_kmer_pos)]
+
+    def raw_arrays(self):
+        """numpy views of the table for the device upload used by the parity tests."""
+        import numpy as np
+
+        n = self.n_kmer_pos
+        tab = np.ctypeslib.as_array(
+            C.cast(self.L.og_index_kmer_pos_table(self.h), C.POINTER(C.c_uint8)), shape=(n * C.sizeof(KmerPos),)
+        ).copy()
+        return tab
+
+    def find_positions_for_query_kmer(self, kmer: str):
+        out = C.POINTER(KmerPos)()
+        n = self.L.og_index_find_positions(self.h, kmer.encode(), len(kmer), C.byref(out))
+        return [out[i].t() for i in range(n)]
+
+    def get_bv_rank(self, pos): return int(self.L.og_index_bv_rank(self.h, pos))
+    def get_bv_inverse_rank(self, pos): return int(self.L.og_index_bv_inverse_rank(self.h, pos))
+    def get_bv_select(self, n): return int(self.L.og_index_bv_select(self.h, n))
+    def node_id_from_seqpos(self, orient, position): return int(self.L.og_index_node_id_from_seqpos(self.h, SeqPos(orient, position)))
+    def handle_from_seqpos(self, orient, position): return int(self.L.og_index_handle_from_seqpos(self.h, SeqPos(orient, position)))
+
+    def seq_from_handle(self, handle: int) -> str:
+        n = self.L.og_index_seq_from_handle(self.h, handle, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.L.og_index_seq_from_handle(self.h, handle, buf, n)
+        return buf.raw[:n].decode()
+
+    def _edges(self, fn, handle):
+        buf = (C.c_uint64 * 4096)()
+        n = fn(self.h, handle, buf, 4096)
+        return [int(buf[i]) for i in range(n)]
+
+    def edges_from_handle(self, h): return self._edges(self.L.og_index_edges_from_handle, h)
+    def incoming_edges_from_handle(self, h): return self._edges(self.L.og_index_incoming_edges, h)
+    def outgoing_edges_from_handle(self, h): return self._edges(self.L.og_index_outgoing_edges, h)
+
+    # --- anchors / chains
+    def anchors_for_query_raw(self, query: str, only_forward: bool = True):
+        out = C.POINTER(Anchor)()
+        n = self.L.og_anchors_for_query(self.h, query.encode(), len(query), 1 if only_forward else 0, C.byref(out))
+        return out, n
+
+    def anchors_for_query(self, query: str, only_forward: bool = True) -> List[AnchorT]:
+        out, n = self.anchors_for_query_raw(query, only_forward)
+        res = [_anchor_t(out[i]) for i in range(n)]
+        if n:
+            self.L.og_free(out)
+        return res
+
+
+def score_anchor(a: AnchorT, b: AnchorT, seed_length: int, max_gap: int) -> float:
+    def mk(x: AnchorT) -> Anchor:
+        return Anchor(x.id, x.query_begin, x.query_end, SeqPos(*x.target_begin), SeqPos(*x.target_end),
+                      x.max_chain_score, x.best_predecessor_id)
+    return float(lib().og_score_anchor(C.byref(mk(a)), C.byref(mk(b)), seed_length, max_gap))
+
+
+@dataclass
+class ChainResult:
+    sorted_anchors: List[AnchorT]      # after the DP, before backtracking
+    chains: List[List[AnchorT]]        # [] for the placeholder chain
+    is_placeholder: List[bool]
+    curr_max: float
+
+
+def chain_anchors(index: Index, query: str, bandwidth=50, max_gap=1000, min_anchors=3, only_forward=True,
+                  keep_raw=False):
+    """anchors_for_query + chain_anchors.  With keep_raw the ChainSet and anchor buffer stay alive."""
+    L = lib()
+    arr, n = index.anchors_for_query_raw(query, only_forward)
+    snap = (Anchor * max(n, 1))()
+    cs = ChainSet()
+    L.og_chain_anchors(arr, n, index.k, bandwidth, max_gap, min_anchors, C.byref(cs), snap)
+    res = ChainResult(
+        [_anchor_t(snap[i]) for i in range(n)],
+        [[_anchor_t(cs.chains[c].anchors[i]) for i in range(cs.chains[c].n)] for c in range(cs.n)],
+        [bool(cs.chains[c].is_placeholder) for c in range(cs.n)],
+        float(cs.curr_max),
+    )
+    if keep_raw:
+        return res, cs, arr
+    L.og_chain_set_free(C.byref(cs))
+    if n:
+        L.og_free(arr)
+    return res
+
+
+@dataclass
+class SubgraphT:
+    range_handles: List[int]
+    orient: int
+    nodes: List[str]
+    edges: List[Tuple[int, int]]
+
+
+def subgraph_for_chain(index: Index, cs: ChainSet, chain_idx: int, query_len: int, extend: bool = True):
+    L = lib()
+    r0, r1, sg = Range(), Range(), Subgraph()
+    ch = cs.chains[chain_idx]
+    rc = L.og_find_range_chain(index.h, C.byref(ch), C.byref(r0))
+    assert rc == 0
+    base = [int(r0.handles[i]) for i in range(r0.n)]
+    if extend:
+        rc = L.og_extend_range_chain_2(index.h, C.byref(ch), query_len, C.byref(r0), C.byref(r1))
+        assert rc == 0
+        use = r1
+    else:
+        use = r0
+    L.og_find_nodes_edges_for_abpoa(index.h, C.byref(use), C.byref(sg))
+    out = SubgraphT(
+        [int(use.handles[i]) for i in range(use.n)],
+        int(use.orient),
+        [sg.seqs[i].decode() for i in range(sg.n_nodes)],
+        [(int(sg.edge_src[i]), int(sg.edge_dst[i])) for i in range(sg.n_edges)],
+    )
+    L.og_subgraph_free(C.byref(sg))
+    L.og_range_free(C.byref(r0))
+    if extend:
+        L.og_range_free(C.byref(r1))
+    return out, base
+
+
+@dataclass
+class PoaT:
+    ok: bool
+    best_score: int
+    abpoa_nodes: List[int]
+    graph_nodes: List[int]
+    aln_start_offset: int
+    aln_end_offset: int
+    n_aligned_bases: int
+    cigar: str
+    cs_string: str
+    n_rows: int
+    n_cells: int
+
+
+def default_poa_params() -> PoaParams:
+    p = PoaParams()
+    lib().og_poa_default_params(C.byref(p))
+    return p
+
+
+def poa_align(nodes: Sequence[str], edges: Sequence[Tuple[int, int]], query: str,
+              params: Optional[PoaParams] = None) -> PoaT:
+    L = lib()
+    p = params or default_poa_params()
+    n = len(nodes)
+    arr = (C.c_char_p * n)(*[s.encode() for s in nodes])
+    lens = (C.c_size_t * n)(*[len(s) for s in nodes])
+    ne = len(edges)
+    es = (C.c_size_t * max(ne, 1))(*[e[0] for e in edges])
+    ed = (C.c_size_t * max(ne, 1))(*[e[1] for e in edges])
+    res = PoaResult()
+    rc = L.og_poa_align(arr, lens, n, es, ed, ne, query.encode(), len(query), C.byref(p), C.byref(res))
+    if rc != 0:
+        raise RuntimeError(f"og_poa_align -> {rc}")
+    out = PoaT(
+        bool(res.ok), int(res.best_score),
+        [int(res.abpoa_nodes[i]) for i in range(res.n_abpoa_nodes)] if res.ok else [],
+        [int(res.graph_nodes[i]) for i in range(res.n_abpoa_nodes)] if res.ok else [],
+        int(res.aln_start_offset), int(res.aln_end_offset), int(res.n_aligned_bases),
+        res.cigar.decode() if res.cigar else "", res.cs_string.decode() if res.cs_string else "",
+        int(res.n_rows), int(res.n_cells),
+    )
+    L.og_poa_result_free(C.byref(res))
+    return out
+
+
+def gaf_placeholder(name: str, qlen: int) -> str:
+    return _take_str(lib().og_gaf_from_placeholder(name.encode(), qlen))
+
+
+def default_map_params(also_align: bool = True) -> MapParams:
+    p = MapParams()
+    lib().og_map_default_params(C.byref(p))
+    p.also_align = 1 if also_align else 0
+    return p
+
+
+def map_reads(index: Index, names: Sequence[str], seqs: Sequence[str], params: Optional[MapParams] = None):
+    """Whole path on the CPU.  Returns (chains_gaf, alignments_gaf, stats dict)."""
+    L = lib()
+    p = params or default_map_params()
+    n = len(seqs)
+    nm = (C.c_char_p * n)(*[s.encode() for s in names])
+    sq = (C.c_char_p * n)(*[s.encode() for s in seqs])
+    cg, ag = C.c_void_p(), C.c_void_p()
+    st = MapStats()
+    rc = L.og_map_reads(index.h, nm, sq, n, C.byref(p), C.byref(cg), C.byref(ag), C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"og_map_reads -> {rc}")
+    stats = {f[0]: getattr(st, f[0]) for f in MapStats._fields_}
+    return _take_str(cg), _take_str(ag), stats
+
+
+def read_seqs_from_file(path: str) -> List[Tuple[str, str]]:
+    """src/io.rs:74-162 (FASTA: every non-empty sequence line is a read; FASTQ: strict 4-line records)."""
+    ext = os.path.splitext(path)[1].lstrip(".")
+    with open(path) as f:
+        lines = [ln.rstrip("\n") for ln in f]
+    out: List[Tuple[str, str]] = []
+    if ext in ("fa", "fasta"):
+        name, count = "", 0
+        for ln in lines:
+            if ln.startswith(">"):
+                name, count = ln[1:], 0
+            elif ln != "":
+                out.append((name if count == 0 else name + str(count), ln))
+                count += 1
+    elif ext in ("fq", "fastq"):
+        for i in range(0, len(lines) - 3, 4):
+            out.append((lines[i][1:], lines[i + 1]))
+    else:
+        raise ValueError("Unrecognized file type")
+    return out
