@@ -1,0 +1,219 @@
+/*
+ * vga_hip.h -- C ABI of libvga_hip.so: the MI355X (gfx950) implementation of rs-vgaligner's
+ * per-read hot path  map.rs -> chain.rs -> align.rs.
+ *
+ * Plain C, plain pointers and sizes, int error codes.  No C++/torch types cross this boundary.
+ * Every entry point names the reference interface it stands in for (paths relative to the
+ * AlgoLab/rs-vgaligner checkout).  A Rust `extern "C"` block binding exactly these symbols is shown
+ * in INTEGRATION.md.
+ *
+ * Ownership: inputs are borrowed for the duration of a call; result objects are allocated by the
+ * library and released with the matching *_free.  Device memory belongs to the ctx.  One ctx per
+ * GPU; calls on one ctx must be serialised by the caller, different ctxs may be driven from
+ * different threads/processes concurrently.  Nothing throws or aborts across the ABI: a negative
+ * return code plus vga_last_error(ctx) replaces the reference's panic!/unwrap().
+ */
+#ifndef VGA_HIP_H
+#define VGA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGA_OK 0
+#define VGA_ERR_ARG (-1)
+#define VGA_ERR_HIP (-2)          /* a HIP runtime call failed (message has the hipError string) */
+#define VGA_ERR_NOMEM (-3)
+#define VGA_ERR_UNSUPPORTED (-4)  /* k > 15, non-ACGT k-mer in the table, bandwidth > 64, ... */
+#define VGA_ERR_NO_INDEX (-5)
+#define VGA_ERR_NO_DEVICE (-6)    /* no gfx950 device visible: the library never falls back to a CPU path */
+#define VGA_ERR_POOL (-7)         /* traceback pool exhausted; retry with a smaller sub-batch */
+
+#define VGA_NO_PRED (-1)
+
+typedef struct vga_ctx vga_ctx;
+
+/* ---- context ---------------------------------------------------------------------------- */
+/* Creates a context on HIP device `device` with a private stream.  Fails with VGA_ERR_NO_DEVICE
+ * when no GPU is present. */
+int vga_ctx_create(int device, vga_ctx **out);
+void vga_ctx_destroy(vga_ctx *ctx);
+const char *vga_last_error(const vga_ctx *ctx);
+/* Blocks until all work queued on the ctx's stream has finished. */
+int vga_ctx_synchronize(vga_ctx *ctx);
+/* ABI version of the library (bumped on any signature change). */
+int vga_abi_version(void);
+
+/* ---- index upload ------------------------------------------------------------------------ */
+/* KmerPos, src/kmer.rs:733-738 (SeqPos = {orient, position}, src/kmer.rs:27-31).
+ * The delimiter record is {1, UINT64_MAX, 1, UINT64_MAX} (src/kmer.rs:740-749). */
+typedef struct {
+    uint64_t start;
+    uint64_t end;
+    uint8_t start_orient; /* 0 Forward, 1 Reverse */
+    uint8_t end_orient;
+} vga_kmerpos;
+
+/* Host view of the fields of `Index` the query side reads (src/index.rs:37-90).  The boomphf MPHF
+ * and the ahash keys are replaced by the k-mer strings themselves: the reference checks exact
+ * membership before it consults the MPHF (src/index.rs:319-320), so an exact map is equivalent. */
+typedef struct {
+    uint32_t kmer_length;          /* Index.kmer_length */
+    uint64_t seq_length;           /* Index.seq_length */
+    const char *seq_fwd;           /* Index.seq_fwd, seq_length bytes */
+    uint64_t n_nodes;              /* Index.n_nodes */
+    const uint64_t *node_seq_idx;  /* NodeRef.seq_idx,       n_nodes+1 (src/utils.rs:15-22) */
+    const uint64_t *node_edge_idx; /* NodeRef.edge_idx,      n_nodes+1 */
+    const uint64_t *node_edges_to; /* NodeRef.edges_to_node, n_nodes+1 */
+    uint64_t n_edges;              /* Index.n_edges */
+    const uint64_t *edges;         /* Index.edges as packed handles (id<<1 | is_reverse) */
+    uint64_t n_kmers;              /* Index.n_kmers */
+    const char *kmer_keys;         /* n_kmers * kmer_length bytes, the distinct k-mers */
+    const uint64_t *kmer_starts;   /* per k-mer: first record in kmer_pos_table (the MPHF's values) */
+    uint64_t n_kmer_pos;           /* Index.n_kmer_pos (records incl. delimiters) */
+    const vga_kmerpos *kmer_pos_table; /* Index.kmer_pos_table */
+} vga_index_desc;
+
+/* Stands in for Index::load_from_file + every per-read Index accessor
+ * (src/index.rs:296-305, 309-382, 388-606): copies the index to HBM once. */
+int vga_index_upload(vga_ctx *ctx, const vga_index_desc *desc);
+
+/* ---- read batches -------------------------------------------------------------------------- */
+typedef struct vga_batch vga_batch;
+/* reads_concat: all read sequences back to back; read_off[i]..read_off[i+1] delimits read i
+ * (n_reads+1 offsets).  Copies the reads to HBM (the Vec<QuerySequence> of src/io.rs:74-162). */
+int vga_batch_create(vga_ctx *ctx, const char *reads_concat, const uint64_t *read_off, uint64_t n_reads,
+                     vga_batch **out);
+void vga_batch_destroy(vga_batch *b);
+
+/* ---- map: anchors + chains ------------------------------------------------------------------ */
+typedef struct {
+    uint32_t bandwidth;           /* 50   (src/subcommands/map_main.rs:103) */
+    uint64_t max_gap;             /* 1000 (map_main.rs:30-34) */
+    uint32_t chain_min_n_anchors; /* 3    (map_main.rs:42-46) */
+    int only_forward;             /* 1    (src/map.rs:62); 0 is not supported yet */
+} vga_map_params;
+void vga_map_default_params(vga_map_params *p);
+
+/* Result of anchors_for_query + chain_anchors for every read of a batch.
+ * Anchors of read r occupy [anchor_off[r], anchor_off[r+1]) and are in the order chain_anchors
+ * leaves them in (stable sort by target_end.position, src/chain.rs:386-389).
+ * Chains of read r are chain_off[r]..chain_off[r+1]; a read with no chain has exactly one
+ * placeholder entry (src/chain.rs:644-649) with chain_len == 0. */
+typedef struct {
+    uint64_t n_reads;
+    uint64_t n_anchors;
+    uint64_t *anchor_off;    /* n_reads+1 */
+    uint32_t *anchor_id;     /* Anchor.id (src/chain.rs:146,162) */
+    uint32_t *query_begin;   /* Anchor.query_begin; query_end = query_begin + k */
+    uint32_t *target_begin;  /* Anchor.target_begin.position (Forward) */
+    uint32_t *target_end;    /* Anchor.target_end.position   (Forward) */
+    double *max_chain_score; /* f(i) after src/chain.rs:403-450 */
+    int32_t *best_pred_id;   /* id of the best predecessor after the DP, VGA_NO_PRED for None */
+    double *curr_max;        /* per read */
+    uint64_t n_chains;
+    uint64_t *chain_off;        /* n_reads+1 */
+    uint8_t *chain_placeholder; /* n_chains */
+    uint64_t *chain_anchor_off; /* n_chains+1, into chain_anchor_idx */
+    uint32_t *chain_anchor_idx; /* index (within the read's sorted anchors) of each chain member, ascending */
+    /* timing of the last call, milliseconds, measured with hipEvents on the ctx stream */
+    float ms_probe, ms_sort, ms_chain, ms_total;
+    uint64_t n_hits;            /* position records touched (H of the byte model) */
+} vga_map_result;
+
+/* Stands in for the pass-1 loop of map_reads: anchors_for_query (src/map.rs:62 -> src/chain.rs:134)
+ * followed by chain_anchors (src/map.rs:79-89 -> src/chain.rs:370). */
+int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map_result **out);
+void vga_map_result_free(vga_map_result *r);
+
+/* ---- align: chain -> subgraph -> POA ---------------------------------------------------------- */
+typedef struct {
+    int32_t match;     /* 2  */
+    int32_t mismatch;  /* 4  */
+    int32_t gap_open1; /* 4  */
+    int32_t gap_ext1;  /* 2  */
+    int32_t gap_open2; /* 24 */
+    int32_t gap_ext2;  /* 1  */
+    int32_t wb;        /* 10, adaptive band: w = wb + floor(wf * qlen); wb < 0 disables banding */
+    double wf;         /* 0.01 */
+} vga_poa_params;
+void vga_poa_default_params(vga_poa_params *p);
+
+/* The fields of ab_poa's AbpoaAlignmentResult that the reference consumes
+ * (src/align.rs:205-206, 1107, 1152-1165), for n problems. */
+typedef struct {
+    uint64_t n;
+    uint8_t *ok;                /* 0: placeholder / no alignment inside the band */
+    int32_t *best_score;
+    uint64_t *path_off;         /* n+1: per problem, range of graph-consuming alignment columns */
+    uint32_t *abpoa_nodes;      /* AbpoaAlignmentResult.abpoa_nodes: 1-based base-row id per column */
+    uint32_t *graph_nodes;      /* AbpoaAlignmentResult.graph_nodes: index of the node string per column */
+    uint32_t *aln_start_offset;
+    uint32_t *aln_end_offset;
+    uint32_t *n_aligned_bases;
+    uint64_t *cigar_off;        /* n+1 */
+    char *cigar;                /* concatenated, each NUL terminated inside its range */
+    uint64_t *cs_off;           /* n+1 */
+    char *cs;                   /* "cs:Z:..." */
+    uint64_t *n_rows;           /* N of the byte model: graph bases in the subgraph */
+    uint64_t *n_cells;          /* C of the byte model: sum of band widths */
+    float ms_dp, ms_traceback, ms_total;
+} vga_poa_result;
+void vga_poa_result_free(vga_poa_result *r);
+
+/* The reference's one real FFI seam:
+ *   AbpoaAligner::create_align_safe(&Vec<&str> nodes, &Vec<(usize,usize)> edges, &str query, Global)
+ * (src/align.rs:173-203), batched over n independent problems.
+ * Problem p owns nodes node_ptr[p] .. node_ptr[p+1]-1; node v is nodes_concat[node_off[v] .. node_off[v+1])
+ * (node_off holds node_ptr[n]+1 absolute offsets: node strings are laid out back to back);
+ * edges edge_ptr[p]..edge_ptr[p+1] are 0-based (src,dst) pairs with src < dst; the query is
+ * queries_concat[query_off[p] .. query_off[p+1]). */
+int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr, const uint64_t *node_off,
+                  const char *nodes_concat, const uint64_t *edge_ptr, const uint32_t *edge_src,
+                  const uint32_t *edge_dst, const uint64_t *query_off, const char *queries_concat,
+                  const vga_poa_params *params, vga_poa_result **out);
+
+/* One alignment record per read: best_alignment_for_query (src/align.rs:34-55) over the chains of
+ * vga_map_batch, i.e. find_range_chain + extend_range_chain_2 + find_nodes_edges_for_abpoa +
+ * create_align_safe + the fields generate_alignment needs (src/align.rs:267-402, 523-665, 670-724,
+ * 202, 1096-1168). */
+typedef struct {
+    uint64_t n_reads;
+    uint8_t *aligned;            /* 0 => placeholder record (src/align.rs:913-930) */
+    uint64_t *path_off;          /* n_reads+1 */
+    uint64_t *path_handles;      /* packed handles of the node path after dedup (src/align.rs:1114-1123) */
+    uint32_t *path_length;       /* abpoa_nodes.len()  (src/align.rs:1152) */
+    uint32_t *path_start;        /* aln_start_offset   (src/align.rs:1155) */
+    uint32_t *path_end;          /* aln_end_offset     (src/align.rs:1156) */
+    uint32_t *block_length;      /* n_aligned_bases    (src/align.rs:1158) */
+    int32_t *best_score;
+    uint64_t *cigar_off;
+    char *cigar;
+    uint64_t *cs_off;
+    char *cs;
+    uint64_t poa_rows, poa_cells, poa_problems; /* totals for the byte model */
+    float ms_subgraph, ms_dp, ms_traceback, ms_total;
+} vga_align_result;
+
+int vga_align_batch(vga_batch *b, const vga_map_result *chains, uint32_t align_best_n,
+                    const vga_poa_params *params, vga_align_result **out);
+void vga_align_result_free(vga_align_result *r);
+
+/* Per-kernel timing of the most recent vga_map_batch / vga_poa_batch / vga_align_batch on this ctx:
+ * name[i] / total milliseconds / launches, measured with hipEvents on the ctx's own stream.
+ * Returns the number of kernels (at most cap entries are written). */
+typedef struct {
+    const char *name;
+    float ms;
+    uint32_t launches;
+    uint64_t algorithmic_bytes; /* byte model of DESIGN.md for the units those launches processed */
+} vga_kernel_time;
+int vga_last_kernel_times(const vga_ctx *ctx, vga_kernel_time *out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -21,7 +21,17 @@
  *     list order wins (list order = order of the input edge list);
  *   - a gap state prefers "open" over "extend" on a tie;
  *   - bases other than upper-case A/C/G/T score 0 against anything;
- *   - cells outside a predecessor's band read as OG_NEG; there is no clamping.
+ *   - cells outside a predecessor's band read as OG_NEG; there is no clamping;
+ *   - recurrences, with Ht = max(M, E1, E2) ("H before insertions"):
+ *       M [r][j] = max_p H[p][j-1] + s(base_r, q_j)
+ *       Ek[r][j] = max_p max(H[p][j] - (Ok+Ek), Ek[p][j] - Ek)          k = 1, 2
+ *       Fk[r][j] = max_{beg <= j' < j} Ht[r][j'] - Ok - Ek*(j - j')      (OG_NEG at j = beg)
+ *       H [r][j] = max(Ht, F1, F2)
+ *     i.e. an insertion run opens from Ht only.  Opening it from a cell whose own value came from
+ *     an insertion is dominated under a convex gap cost (O1,O2 >= 0, E2 <= E1), so H is unchanged,
+ *     and Fk becomes a max-plus prefix scan of the row -- the form the GPU kernel evaluates;
+ *   - traceback is a state machine over {H, Ht, E1, E2, F1, F2}: leaving an insertion run by its
+ *     "open" edge lands in state Ht of the cell to the left.
  */
 #include "og_internal.h"
 
@@ -155,7 +165,7 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
     int64_t *end = (int64_t *)malloc((N + 2) * sizeof(int64_t));
     size_t *off = (size_t *)malloc((N + 2) * sizeof(size_t));
     size_t cells = 0, ccap = 0;
-    int32_t *H = NULL, *E1 = NULL, *E2 = NULL, *F1 = NULL, *F2 = NULL;
+    int32_t *H = NULL, *HT = NULL, *E1 = NULL, *E2 = NULL, *F1 = NULL, *F2 = NULL;
 
     size_t pbuf_cap = 64;
     size_t *preds = (size_t *)malloc(pbuf_cap * sizeof(size_t));
@@ -177,6 +187,7 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
             size_t nc = ccap ? ccap : (1u << 20);
             while (nc < cells + width) nc *= 2;
             H = (int32_t *)realloc(H, nc * sizeof(int32_t));
+            HT = (int32_t *)realloc(HT, nc * sizeof(int32_t));
             E1 = (int32_t *)realloc(E1, nc * sizeof(int32_t));
             E2 = (int32_t *)realloc(E2, nc * sizeof(int32_t));
             F1 = (int32_t *)realloc(F1, nc * sizeof(int32_t));
@@ -185,7 +196,7 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
         }
         cells += width;
         if (r > 0) n_cells_rows += width;
-        int32_t *h = H + off[r], *pe1 = E1 + off[r], *pe2 = E2 + off[r], *f1 = F1 + off[r], *f2 = F2 + off[r];
+        int32_t *h = H + off[r], *ht = HT + off[r], *pe1 = E1 + off[r], *pe2 = E2 + off[r], *f1 = F1 + off[r], *f2 = F2 + off[r];
 
         /* predecessors of this row */
         size_t np = 0;
@@ -202,16 +213,14 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
 
         int32_t rmax = INT32_MIN;
         int64_t lmax = b, rmaxpos = b;
+        /* running maxima of Ht[j'] + Ek*j' over the columns already visited (the prefix scan) */
+        int have_run = 0;
+        int64_t run1 = 0, run2 = 0;
         for (int64_t j = b; j <= e; j++) {
             size_t c = (size_t)(j - b);
-            int32_t m = OG_NEG, ve1 = OG_NEG, ve2 = OG_NEG, vf1 = OG_NEG, vf2 = OG_NEG, vh;
+            int32_t m = OG_NEG, ve1 = OG_NEG, ve2 = OG_NEG, vf1 = OG_NEG, vf2 = OG_NEG, vht, vh;
             if (r == 0) {
-                if (j == 0) vh = 0;
-                else {
-                    vf1 = -(P->gap_open1 + (int32_t)j * e1);
-                    vf2 = -(P->gap_open2 + (int32_t)j * e2);
-                    vh = vf1 > vf2 ? vf1 : vf2;
-                }
+                vht = j == 0 ? 0 : OG_NEG;
             } else {
                 char gb = row_base[r];
                 for (size_t t = 0; t < np; t++) {
@@ -230,19 +239,24 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
                         if (c2 > ve2) ve2 = c2;
                     }
                 }
-                if (j - 1 >= b) {
-                    int32_t a1 = h[c - 1] - oe1, b1 = f1[c - 1] - e1;
-                    vf1 = a1 > b1 ? a1 : b1;
-                    int32_t a2 = h[c - 1] - oe2, b2 = f2[c - 1] - e2;
-                    vf2 = a2 > b2 ? a2 : b2;
-                }
-                vh = m;
-                if (ve1 > vh) vh = ve1;
-                if (ve2 > vh) vh = ve2;
-                if (vf1 > vh) vh = vf1;
-                if (vf2 > vh) vh = vf2;
+                vht = m;
+                if (ve1 > vht) vht = ve1;
+                if (ve2 > vht) vht = ve2;
             }
-            h[c] = vh; pe1[c] = ve1; pe2[c] = ve2; f1[c] = vf1; f2[c] = vf2;
+            if (have_run) {
+                vf1 = (int32_t)(run1 - P->gap_open1 - (int64_t)e1 * j);
+                vf2 = (int32_t)(run2 - P->gap_open2 - (int64_t)e2 * j);
+            }
+            vh = vht;
+            if (vf1 > vh) vh = vf1;
+            if (vf2 > vh) vh = vf2;
+            {
+                int64_t a1 = (int64_t)vht + (int64_t)e1 * j, a2 = (int64_t)vht + (int64_t)e2 * j;
+                if (!have_run || a1 > run1) run1 = a1;
+                if (!have_run || a2 > run2) run2 = a2;
+                have_run = 1;
+            }
+            h[c] = vh; ht[c] = vht; pe1[c] = ve1; pe2[c] = ve2; f1[c] = vf1; f2[c] = vf2;
             if (vh > rmax) { rmax = vh; lmax = j; rmaxpos = j; }
             else if (vh == rmax) rmaxpos = j;
         }
@@ -296,7 +310,7 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
         uint32_t *oq = (uint32_t *)malloc(ocap * sizeof(uint32_t));
         size_t i = best_row;
         int64_t j = qlen;
-        int st = 0; /* 0=H 1=E1 2=E2 3=F1 4=F2 */
+        int st = 0; /* 0=H 1=E1 2=E2 3=F1 4=F2 5=Ht */
         int bad = 0;
         while (i > 0 && !bad) {
             /* predecessors of row i */
@@ -306,8 +320,8 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
             else if (in_off[v + 1] == in_off[v]) preds[np++] = 0;
             else for (size_t t = in_off[v]; t < in_off[v + 1]; t++) preds[np++] = last_row[in_adj[t]];
             size_t c = off[i] + (size_t)(j - beg[i]);
-            if (st == 0) {
-                int32_t hv = H[c];
+            if (st == 0 || st == 5) {
+                int32_t hv = st == 0 ? H[c] : HT[c];
                 int found = 0;
                 if (j >= 1) {
                     int32_t s = og_sub(P, row_base[i], query[j - 1]);
@@ -315,15 +329,15 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
                         size_t p = preds[t];
                         if (j - 1 >= beg[p] && j - 1 <= end[p] && H[off[p] + (size_t)(j - 1 - beg[p])] + s == hv) {
                             ops[on] = 'M'; orow[on] = (uint32_t)i; oq[on] = (uint32_t)(j - 1); on++;
-                            i = p; j = j - 1; found = 1;
+                            i = p; j = j - 1; found = 1; st = 0;
                         }
                     }
                 }
                 if (!found) {
                     if (E1[c] == hv) st = 1;
                     else if (E2[c] == hv) st = 2;
-                    else if (F1[c] == hv) st = 3;
-                    else if (F2[c] == hv) st = 4;
+                    else if (st == 0 && F1[c] == hv) st = 3;
+                    else if (st == 0 && F2[c] == hv) st = 4;
                     else bad = 1;
                 }
             } else if (st == 1 || st == 2) {
@@ -351,7 +365,7 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
                 int32_t fv = F[c];
                 if (j - 1 < beg[i]) { bad = 1; break; }
                 ops[on] = 'I'; orow[on] = 0; oq[on] = (uint32_t)(j - 1); on++;
-                if (H[c - 1] - oe == fv) st = 0;
+                if (HT[c - 1] - oe == fv) st = 5;
                 j = j - 1;
             }
             if (on + 2 >= ocap) { bad = 1; }
@@ -426,6 +440,6 @@ cleanup:
     free(first_row); free(last_row); free(row_base); free(row_node);
     free(in_off); free(out_off); free(in_adj); free(out_adj);
     free(remain); free(mpl); free(mpr); free(beg); free(end); free(off);
-    free(H); free(E1); free(E2); free(F1); free(F2); free(preds);
+    free(H); free(HT); free(E1); free(E2); free(F1); free(F2); free(preds);
     return OG_OK;
 }

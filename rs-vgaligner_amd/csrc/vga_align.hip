@@ -1,0 +1,355 @@
+// vga_align.hip -- chain -> subgraph -> POA problem -> one alignment record per read.
+//
+// Stands in for best_alignment_for_query / obtain_base_level_alignment (src/align.rs:34-145):
+//   find_range_chain ............ src/align.rs:267-402   (u64::from(Handle) read as the node id)
+//   extend_range_chain_2 ........ src/align.rs:523-665
+//   find_nodes_edges_for_abpoa .. src/align.rs:670-724
+//   create_align_safe ........... src/align.rs:202        -> vga_poa_batch (vga_poa.hip)
+//   generate_alignment .......... src/align.rs:1096-1168  (fields only; the GAF text is host code)
+// The subgraph extraction is light integer work over the index's CSR arrays (src/index.rs:388-606)
+// and runs on host threads while the GPU is busy with the DP of the previous call; moving it to the
+// device is listed under "next" in DESIGN.md.  The ./subgraphs/*.gfa export side effect of
+// align.rs:104-111 is a debugging aid and is not reproduced.
+#include "vga_common.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <thread>
+
+namespace {
+
+typedef uint32_t handle_t;  // (id << 1) | is_reverse
+
+struct index_view {
+    const vga_dev_index &ix;
+    explicit index_view(const vga_dev_index &i) : ix(i) {}
+
+    // get_bv_rank over the node-start bit vector (src/index.rs:427-439): starts <= pos
+    uint32_t rank(uint32_t pos) const
+    {
+        return (uint32_t)(std::upper_bound(ix.node_start.begin(), ix.node_start.end(), pos) - ix.node_start.begin());
+    }
+    // handle_from_seqpos for a Forward position (src/index.rs:415-423)
+    handle_t handle_from_fwd_pos(uint32_t pos) const { return rank(pos) * 2; }
+    // get_bv_select (src/index.rs:461-480)
+    uint32_t select(uint32_t element_no) const
+    {
+        if (element_no == 0 || element_no > ix.n_nodes + 1) return 0;
+        return ix.node_start[element_no - 1];
+    }
+    uint32_t node_len(handle_t h) const
+    {
+        uint32_t id = h >> 1;
+        return ix.node_start[id] - ix.node_start[id - 1];
+    }
+    // incoming_edges_from_handle / outgoing_edges_from_handle (src/index.rs:559-606)
+    void incoming(handle_t h, std::vector<handle_t> &out) const
+    {
+        out.clear();
+        uint32_t pos = (h >> 1) - 1;
+        if (!(h & 1)) {
+            uint32_t s = ix.edge_idx[pos], n = ix.edges_to[pos];
+            for (uint32_t i = 0; i < n; i++) out.push_back(ix.edges[s + i]);
+        } else {
+            outgoing(h ^ 1, out);
+            for (auto &x : out) x ^= 1;
+            std::reverse(out.begin(), out.end());
+        }
+    }
+    void outgoing(handle_t h, std::vector<handle_t> &out) const
+    {
+        out.clear();
+        uint32_t pos = (h >> 1) - 1;
+        if (!(h & 1)) {
+            uint32_t s = ix.edge_idx[pos] + ix.edges_to[pos], e = ix.edge_idx[pos + 1];
+            for (uint32_t i = s; i < e; i++) out.push_back(ix.edges[i]);
+        } else {
+            incoming(h ^ 1, out);
+            for (auto &x : out) x ^= 1;
+            std::reverse(out.begin(), out.end());
+        }
+    }
+    // seq_from_handle (src/index.rs:503-533); the reverse strand is derived as dna.rs:19-33 does
+    void append_seq(handle_t h, std::string &out) const
+    {
+        uint32_t id = h >> 1;
+        uint32_t s = ix.node_start[id - 1], e = ix.node_start[id];
+        if (!(h & 1)) out.append(ix.seq_fwd.data() + s, e - s);
+        else
+            for (uint32_t i = e; i-- > s;) {
+                char c = ix.seq_fwd[i], r;
+                switch (c) {
+                case 'a': r = 't'; break; case 'c': r = 'g'; break; case 't': r = 'a'; break; case 'g': r = 'c'; break;
+                case 'u': r = 'a'; break; case 'A': r = 'T'; break; case 'C': r = 'G'; break; case 'T': r = 'A'; break;
+                case 'G': r = 'C'; break; case 'U': r = 'A'; break; default: r = 'N';
+                }
+                out.push_back(r);
+            }
+    }
+};
+
+struct subgraph_t {
+    std::vector<handle_t> handles;  // sorted, deduplicated (src/align.rs:658-659)
+    std::vector<uint64_t> node_off; // per node: offset into seqs (n+1)
+    std::string seqs;
+    std::vector<uint32_t> esrc, edst;
+};
+
+struct scratch_t {
+    std::vector<uint32_t> best;      // per packed handle: largest remaining budget seen
+    std::vector<handle_t> touched;
+    std::vector<std::pair<uint32_t, handle_t>> cur, next;
+    std::vector<handle_t> nb;
+};
+
+// one direction of src/align.rs:551-591 / 616-656.  The reference's walk keeps no visited set (its
+// frontier grows exponentially on bubble chains); a handle ends up in the range iff it is reachable
+// with a positive remaining budget, which is what the per-handle best-budget relaxation computes.
+void extend_dir(const index_view &iv, handle_t from, uint32_t diff, bool incoming, std::vector<handle_t> &hs, scratch_t &sc)
+{
+    sc.cur.clear();
+    if (incoming) iv.incoming(from, sc.nb); else iv.outgoing(from, sc.nb);
+    for (handle_t h : sc.nb) sc.cur.emplace_back(diff, h);
+    while (!sc.cur.empty()) {
+        sc.next.clear();
+        for (auto &it : sc.cur) {
+            uint32_t left = it.first;
+            handle_t h = it.second;
+            if (sc.best[h] >= left) continue;
+            if (sc.best[h] == 0) { hs.push_back(h); sc.touched.push_back(h); }
+            sc.best[h] = left;
+            uint32_t len = iv.node_len(h);
+            if (len < left) {
+                uint32_t rem = left - len;
+                if (incoming) iv.incoming(h, sc.nb); else iv.outgoing(h, sc.nb);
+                for (handle_t x : sc.nb) sc.next.emplace_back(rem, x);
+            }
+        }
+        sc.cur.swap(sc.next);
+    }
+    for (handle_t h : sc.touched) sc.best[h] = 0;
+    sc.touched.clear();
+}
+
+// find_range_chain + extend_range_chain_2 + find_nodes_edges_for_abpoa for one chain
+void build_subgraph(const index_view &iv, const vga_map_result *m, uint64_t read, uint64_t chain, uint32_t k, uint32_t qlen,
+                    subgraph_t &sg, scratch_t &sc)
+{
+    const uint64_t a0 = m->anchor_off[read];
+    const uint64_t c0 = m->chain_anchor_off[chain], c1 = m->chain_anchor_off[chain + 1];
+    handle_t min_h = 0xFFFFFFFFu, max_h = 0;
+    for (uint64_t t = c0; t < c1; t++) {
+        const uint64_t ai = a0 + m->chain_anchor_idx[t];
+        handle_t s = iv.handle_from_fwd_pos(m->target_begin[ai]);
+        handle_t e = iv.handle_from_fwd_pos(m->target_end[ai] - 1);  // get_end_seqpos_inclusive, chain.rs:65-70
+        min_h = std::min(min_h, std::min(s, e));
+        max_h = std::max(max_h, std::max(s, e));
+    }
+    sg.handles.clear();
+    for (uint32_t x = min_h >> 1; x <= (max_h >> 1); x++) sg.handles.push_back(x * 2);  // align.rs:358-364
+    const handle_t first_handle = sg.handles.front(), last_handle = sg.handles.back();
+    const uint64_t fa = a0 + m->chain_anchor_idx[c0], la = a0 + m->chain_anchor_idx[c1 - 1];
+    // align.rs:536-547
+    uint32_t prefix_diff = m->query_begin[fa];
+    uint32_t start_prefix_on_node = m->target_begin[fa] - iv.select(first_handle >> 1);
+    if (start_prefix_on_node < prefix_diff) prefix_diff -= start_prefix_on_node; else prefix_diff = 0;
+    if (prefix_diff > 0) extend_dir(iv, first_handle, prefix_diff, true, sg.handles, sc);
+    // align.rs:593-612
+    uint32_t suffix_diff = qlen - (m->query_begin[la] + k);
+    uint32_t end_suffix_on_node = iv.select((last_handle >> 1) + 1) - 1 - (m->target_end[la] - 1);
+    if (end_suffix_on_node > suffix_diff) suffix_diff = 0; else suffix_diff -= end_suffix_on_node;
+    if (suffix_diff > 0) extend_dir(iv, last_handle, suffix_diff, false, sg.handles, sc);
+    std::sort(sg.handles.begin(), sg.handles.end());
+    sg.handles.erase(std::unique(sg.handles.begin(), sg.handles.end()), sg.handles.end());
+    // align.rs:670-724
+    sg.seqs.clear();
+    sg.node_off.assign(1, 0);
+    for (handle_t h : sg.handles) { iv.append_seq(h, sg.seqs); sg.node_off.push_back(sg.seqs.size()); }
+    sg.esrc.clear();
+    sg.edst.clear();
+    for (uint32_t i = 0; i < sg.handles.size(); i++) {
+        iv.outgoing(sg.handles[i], sc.nb);
+        for (handle_t t : sc.nb) {
+            auto it = std::lower_bound(sg.handles.begin(), sg.handles.end(), t);
+            if (it == sg.handles.end() || *it != t) continue;
+            uint32_t e = (uint32_t)(it - sg.handles.begin());
+            if (i < e) { sg.esrc.push_back(i); sg.edst.push_back(e); }  // RangeOrient::Forward, align.rs:718
+        }
+    }
+}
+
+template <typename T>
+T *amalloc(size_t n)
+{
+    return (T *)malloc((n ? n : 1) * sizeof(T));
+}
+
+}  // namespace
+
+extern "C" void vga_align_result_free(vga_align_result *r)
+{
+    if (!r) return;
+    free(r->aligned); free(r->path_off); free(r->path_handles); free(r->path_length); free(r->path_start);
+    free(r->path_end); free(r->block_length); free(r->best_score); free(r->cigar_off); free(r->cigar);
+    free(r->cs_off); free(r->cs);
+    free(r);
+}
+
+extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t align_best_n, const vga_poa_params *params,
+                               vga_align_result **out)
+{
+    if (!b || !m || !params || !out) return VGA_ERR_ARG;
+    vga_ctx *ctx = b->ctx;
+    *out = nullptr;
+    if (!ctx->index.loaded) return vga_set_error(ctx, VGA_ERR_NO_INDEX, "vga_align_batch: no index uploaded");
+    if (m->n_reads != b->n_reads) return vga_set_error(ctx, VGA_ERR_ARG, "vga_align_batch: chains belong to a different batch");
+    const uint64_t R = b->n_reads;
+    const uint32_t k = ctx->index.k;
+    auto t0 = std::chrono::steady_clock::now();
+
+    // ---- which (read, chain) pairs become POA problems: first min(best_n, len) chains (align.rs:43-50)
+    std::vector<uint64_t> prob_read, prob_chain;
+    std::vector<uint64_t> read_prob0(R + 1, 0);
+    for (uint64_t r = 0; r < R; r++) {
+        read_prob0[r] = prob_read.size();
+        uint64_t c0 = m->chain_off[r], c1 = m->chain_off[r + 1];
+        uint64_t take = std::min<uint64_t>(align_best_n, c1 - c0);
+        for (uint64_t c = c0; c < c0 + take; c++)
+            if (!m->chain_placeholder[c]) { prob_read.push_back(r); prob_chain.push_back(c); }
+    }
+    read_prob0[R] = prob_read.size();
+    const uint64_t n = prob_read.size();
+
+    // ---- subgraphs (host threads)
+    std::vector<subgraph_t> SG(n);
+    {
+        unsigned nt = std::thread::hardware_concurrency();
+        if (nt == 0) nt = 4;
+        if (nt > 32) nt = 32;
+        if ((uint64_t)nt > n) nt = (unsigned)std::max<uint64_t>(n, 1);
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++)
+            th.emplace_back([&, t]() {
+                index_view iv(ctx->index);
+                scratch_t sc;
+                sc.best.assign((size_t)(ctx->index.n_nodes + 2) * 2, 0);
+                for (uint64_t p = t; p < n; p += nt) {
+                    uint64_t r = prob_read[p];
+                    build_subgraph(iv, m, r, prob_chain[p], k, (uint32_t)(b->read_off[r + 1] - b->read_off[r]), SG[p], sc);
+                }
+            });
+        for (auto &x : th) x.join();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+
+    // ---- flatten into the create_align_safe batch form.  Node strings of consecutive problems are laid
+    // out back to back, so node_off needs only one trailing end offset for the whole batch.
+    std::vector<uint64_t> edge_ptr(n + 1, 0), query_off(n + 1, 0), nptr(n + 1, 0), noff;
+    uint64_t tot_edges = 0, tot_seq = 0, tot_q = 0;
+    for (uint64_t p = 0; p < n; p++) {
+        edge_ptr[p] = tot_edges; query_off[p] = tot_q;
+        tot_edges += SG[p].esrc.size();
+        tot_seq += SG[p].seqs.size();
+        tot_q += b->read_off[prob_read[p] + 1] - b->read_off[prob_read[p]];
+    }
+    edge_ptr[n] = tot_edges; query_off[n] = tot_q;
+    std::string nodes_concat;
+    nodes_concat.reserve(tot_seq);
+    std::vector<uint32_t> esrc, edst;
+    esrc.reserve(tot_edges); edst.reserve(tot_edges);
+    std::string queries;
+    queries.reserve(tot_q);
+    for (uint64_t p = 0; p < n; p++) {
+        nptr[p] = noff.size();
+        const uint64_t base = nodes_concat.size();
+        for (size_t v = 0; v < SG[p].handles.size(); v++) noff.push_back(base + SG[p].node_off[v]);
+        nodes_concat += SG[p].seqs;
+        esrc.insert(esrc.end(), SG[p].esrc.begin(), SG[p].esrc.end());
+        edst.insert(edst.end(), SG[p].edst.begin(), SG[p].edst.end());
+        const uint64_t r = prob_read[p];
+        queries.append(b->reads.data() + b->read_off[r], b->read_off[r + 1] - b->read_off[r]);
+    }
+    nptr[n] = noff.size();
+    noff.push_back(nodes_concat.size());
+
+    vga_poa_result *pr = nullptr;
+    if (n > 0) {
+        int rc = vga_poa_batch(ctx, n, nptr.data(), noff.data(), nodes_concat.data(), edge_ptr.data(), esrc.data(), edst.data(),
+                               query_off.data(), queries.data(), params, &pr);
+        if (rc != VGA_OK) return rc;
+    }
+
+    // ---- per read: keep the candidate with the longest path (stable, align.rs:52-54)
+    vga_align_result *res = (vga_align_result *)calloc(1, sizeof(vga_align_result));
+    res->n_reads = R;
+    res->aligned = amalloc<uint8_t>(R);
+    res->path_off = amalloc<uint64_t>(R + 1);
+    res->path_length = amalloc<uint32_t>(R);
+    res->path_start = amalloc<uint32_t>(R);
+    res->path_end = amalloc<uint32_t>(R);
+    res->block_length = amalloc<uint32_t>(R);
+    res->best_score = amalloc<int32_t>(R);
+    res->cigar_off = amalloc<uint64_t>(R + 1);
+    res->cs_off = amalloc<uint64_t>(R + 1);
+    std::vector<int64_t> pick(R, -1);
+    uint64_t tp = 0, tc = 0, ts = 0;
+    std::vector<std::vector<uint64_t>> paths(R);
+    for (uint64_t r = 0; r < R; r++) {
+        int64_t best = -1;
+        for (uint64_t p = read_prob0[r]; p < read_prob0[r + 1]; p++) {
+            if (!pr->ok[p]) continue;
+            uint64_t plen = pr->path_off[p + 1] - pr->path_off[p];
+            if (best < 0 || plen > pr->path_off[best + 1] - pr->path_off[best]) best = (int64_t)p;
+        }
+        pick[r] = best;
+        res->aligned[r] = best >= 0;
+        res->path_off[r] = tp; res->cigar_off[r] = tc; res->cs_off[r] = ts;
+        res->path_length[r] = res->path_start[r] = res->path_end[r] = res->block_length[r] = 0;
+        res->best_score[r] = 0;
+        if (best >= 0) {
+            const uint64_t p = (uint64_t)best;
+            // graph_nodes.dedup() -> range.handles[idx] (align.rs:1107-1123)
+            uint32_t prev = 0xFFFFFFFFu;
+            for (uint64_t t = pr->path_off[p]; t < pr->path_off[p + 1]; t++) {
+                uint32_t gn = pr->graph_nodes[t];
+                if (t > pr->path_off[p] && gn == prev) continue;
+                prev = gn;
+                paths[r].push_back(SG[p].handles[gn]);
+            }
+            tp += paths[r].size();
+            tc += pr->cigar_off[p + 1] - pr->cigar_off[p];
+            ts += pr->cs_off[p + 1] - pr->cs_off[p];
+            res->path_length[r] = (uint32_t)(pr->path_off[p + 1] - pr->path_off[p]);
+            res->path_start[r] = pr->aln_start_offset[p];
+            res->path_end[r] = pr->aln_end_offset[p];
+            res->block_length[r] = pr->n_aligned_bases[p];
+            res->best_score[r] = pr->best_score[p];
+        } else {
+            tc += 1; ts += 1;
+        }
+    }
+    res->path_off[R] = tp; res->cigar_off[R] = tc; res->cs_off[R] = ts;
+    res->path_handles = amalloc<uint64_t>(tp);
+    res->cigar = amalloc<char>(tc);
+    res->cs = amalloc<char>(ts);
+    for (uint64_t r = 0; r < R; r++) {
+        for (size_t t = 0; t < paths[r].size(); t++) res->path_handles[res->path_off[r] + t] = paths[r][t];
+        if (pick[r] >= 0) {
+            const uint64_t p = (uint64_t)pick[r];
+            memcpy(res->cigar + res->cigar_off[r], pr->cigar + pr->cigar_off[p], pr->cigar_off[p + 1] - pr->cigar_off[p]);
+            memcpy(res->cs + res->cs_off[r], pr->cs + pr->cs_off[p], pr->cs_off[p + 1] - pr->cs_off[p]);
+        } else {
+            res->cigar[res->cigar_off[r]] = 0;
+            res->cs[res->cs_off[r]] = 0;
+        }
+    }
+    res->poa_problems = n;
+    for (uint64_t p = 0; p < n; p++) { res->poa_rows += pr->n_rows[p]; res->poa_cells += pr->n_cells[p]; }
+    res->ms_subgraph = (float)std::chrono::duration<double, std::milli>(t1 - t0).count();
+    res->ms_dp = pr ? pr->ms_dp : 0.f;
+    res->ms_traceback = pr ? pr->ms_traceback : 0.f;
+    res->ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    vga_poa_result_free(pr);
+    *out = res;
+    return VGA_OK;
+}

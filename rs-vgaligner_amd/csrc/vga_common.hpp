@@ -1,0 +1,114 @@
+// vga_common.hpp -- internal definitions of libvga_hip (context, device buffers, event timing).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vga_hip.h"
+
+#define VGA_ABI_VERSION 1
+
+struct vga_dev_index {
+    uint32_t k = 0;
+    uint64_t seq_length = 0;
+    uint64_t n_nodes = 0, n_edges = 0;
+    // k-mer probe: direct-address table on the 2-bit packed k-mer.
+    // table[key] = index of the group's header word pair in pos (or 0xFFFFFFFF);
+    // pos[h] = {count, 0}, pos[h+1..h+count] = {target_begin, target_end} of the forward/forward
+    // records in table order (src/kmer.rs:894 order, src/chain.rs:154 filter).
+    uint32_t *d_table = nullptr;
+    uint64_t table_entries = 0;
+    uint2 *d_pos = nullptr;
+    uint64_t n_pos_words = 0;
+    // host copies used by the subgraph extraction (src/align.rs:267-724)
+    std::vector<char> seq_fwd;
+    std::vector<uint32_t> node_start;  // n_nodes+1
+    std::vector<uint32_t> edge_idx;    // n_nodes+1
+    std::vector<uint32_t> edges_to;    // n_nodes+1
+    std::vector<uint32_t> edges;       // packed handles
+    bool loaded = false;
+};
+
+struct vga_timer_entry {
+    const char *name;
+    hipEvent_t e0, e1;
+    uint64_t bytes;
+};
+
+struct vga_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    vga_dev_index index;
+    // per-call kernel timing (events recorded on `stream`)
+    std::vector<vga_timer_entry> timers;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    struct agg_t {
+        std::string name;
+        float ms;
+        uint32_t launches;
+        uint64_t bytes;
+    };
+    std::vector<agg_t> last_times;
+    int n_cu = 256;
+};
+
+struct vga_batch {
+    vga_ctx *ctx = nullptr;
+    uint64_t n_reads = 0;
+    uint64_t total_bases = 0;
+    std::vector<uint64_t> read_off;  // host copy
+    std::vector<char> reads;         // host copy (subgraph extraction + cs strings need the bases)
+    char *d_reads = nullptr;
+    uint64_t *d_read_off = nullptr;
+};
+
+int vga_set_error(vga_ctx *ctx, int code, const char *fmt, ...);
+
+#define VGA_HIP_CHECK(ctx, call)                                                               \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return vga_set_error((ctx), VGA_ERR_HIP, "%s failed: %s (%s:%d)", #call,           \
+                                 hipGetErrorString(e_), __FILE__, __LINE__);                   \
+    } while (0)
+
+// grow-only device buffer
+template <typename T>
+struct vga_dbuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    ~vga_dbuf() { release(); }
+};
+
+// event timing helpers (vga_ctx.hip)
+void vga_timers_reset(vga_ctx *ctx);
+int vga_timer_begin(vga_ctx *ctx, const char *name, uint64_t bytes);  // returns timer index
+void vga_timer_end(vga_ctx *ctx, int idx);
+void vga_timers_collect(vga_ctx *ctx);  // requires the stream to be synchronised
+float vga_timer_sum(const vga_ctx *ctx, const char *prefix);

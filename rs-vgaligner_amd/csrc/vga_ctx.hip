@@ -1,0 +1,301 @@
+// vga_ctx.hip -- context, error reporting, hipEvent kernel timing, index upload, read batches.
+//
+// Index upload stands in for Index::load_from_file and the query-side accessors of src/index.rs
+// (309-382 lookup, 388-480 rank/select, 489-606 sequence/edges).  The boomphf MPHF + ahash keys
+// (src/index.rs:71,236, src/kmer.rs:931-934) are replaced by a direct-address table on the 2-bit
+// packed k-mer: the reference tests exact membership (index.rs:319) before asking the MPHF, so any
+// exact map gives the same answers, and 4^11 * 4 B = 16 MiB sits in the 256 MiB Infinity Cache.
+#include "vga_common.hpp"
+
+int vga_set_error(vga_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+extern "C" int vga_abi_version(void) { return VGA_ABI_VERSION; }
+
+extern "C" const char *vga_last_error(const vga_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int vga_ctx_create(int device, vga_ctx **out)
+{
+    if (!out) return VGA_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0 || device < 0 || device >= n) return VGA_ERR_NO_DEVICE;
+    vga_ctx *ctx = new vga_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return VGA_ERR_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return VGA_ERR_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    *out = ctx;
+    return VGA_OK;
+}
+
+static void vga_index_release(vga_dev_index &ix)
+{
+    if (ix.d_table) (void)hipFree(ix.d_table);
+    if (ix.d_pos) (void)hipFree(ix.d_pos);
+    ix = vga_dev_index();
+}
+
+extern "C" void vga_ctx_destroy(vga_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    vga_index_release(ctx->index);
+    for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int vga_ctx_synchronize(vga_ctx *ctx)
+{
+    if (!ctx) return VGA_ERR_ARG;
+    VGA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return VGA_OK;
+}
+
+// ---------------------------------------------------------------- timing
+static hipEvent_t vga_event_get(vga_ctx *ctx)
+{
+    if (ctx->events_used == ctx->event_pool.size()) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return nullptr;
+        ctx->event_pool.push_back(ev);
+    }
+    return ctx->event_pool[ctx->events_used++];
+}
+
+void vga_timers_reset(vga_ctx *ctx)
+{
+    ctx->timers.clear();
+    ctx->events_used = 0;
+}
+
+int vga_timer_begin(vga_ctx *ctx, const char *name, uint64_t bytes)
+{
+    vga_timer_entry t;
+    t.name = name;
+    t.bytes = bytes;
+    t.e0 = vga_event_get(ctx);
+    t.e1 = vga_event_get(ctx);
+    if (t.e0) (void)hipEventRecord(t.e0, ctx->stream);
+    ctx->timers.push_back(t);
+    return (int)ctx->timers.size() - 1;
+}
+
+void vga_timer_end(vga_ctx *ctx, int idx)
+{
+    if (idx < 0 || (size_t)idx >= ctx->timers.size()) return;
+    if (ctx->timers[idx].e1) (void)hipEventRecord(ctx->timers[idx].e1, ctx->stream);
+}
+
+void vga_timers_collect(vga_ctx *ctx)
+{
+    ctx->last_times.clear();
+    for (const vga_timer_entry &t : ctx->timers) {
+        float ms = 0.f;
+        if (t.e0 && t.e1) (void)hipEventElapsedTime(&ms, t.e0, t.e1);
+        bool found = false;
+        for (auto &a : ctx->last_times)
+            if (a.name == t.name) {
+                a.ms += ms;
+                a.launches += 1;
+                a.bytes += t.bytes;
+                found = true;
+                break;
+            }
+        if (!found) ctx->last_times.push_back({t.name, ms, 1u, t.bytes});
+    }
+}
+
+float vga_timer_sum(const vga_ctx *ctx, const char *prefix)
+{
+    float s = 0.f;
+    size_t n = strlen(prefix);
+    for (const auto &a : ctx->last_times)
+        if (a.name.compare(0, n, prefix) == 0) s += a.ms;
+    return s;
+}
+
+extern "C" int vga_last_kernel_times(const vga_ctx *ctx, vga_kernel_time *out, int cap)
+{
+    if (!ctx) return 0;
+    int n = (int)ctx->last_times.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        out[i].name = ctx->last_times[i].name.c_str();
+        out[i].ms = ctx->last_times[i].ms;
+        out[i].launches = ctx->last_times[i].launches;
+        out[i].algorithmic_bytes = ctx->last_times[i].bytes;
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------- index upload
+static inline int vga_base_code(char c)
+{
+    switch (c) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    default: return -1;
+    }
+}
+
+extern "C" int vga_index_upload(vga_ctx *ctx, const vga_index_desc *d)
+{
+    if (!ctx || !d) return VGA_ERR_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (d->kmer_length == 0 || d->kmer_length > 15)
+        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "kmer_length %u: the direct-address probe table supports 1..15",
+                             d->kmer_length);
+    if (d->seq_length >= (1ull << 31) || d->n_nodes >= (1ull << 30) || d->n_edges >= (1ull << 31))
+        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "graph too large for 32-bit device coordinates");
+    if (!d->seq_fwd || !d->node_seq_idx || !d->node_edge_idx || !d->node_edges_to || (!d->edges && d->n_edges) ||
+        !d->kmer_keys || !d->kmer_starts || !d->kmer_pos_table)
+        return vga_set_error(ctx, VGA_ERR_ARG, "null array in vga_index_desc");
+
+    vga_index_release(ctx->index);
+    vga_dev_index &ix = ctx->index;
+    ix.k = d->kmer_length;
+    ix.seq_length = d->seq_length;
+    ix.n_nodes = d->n_nodes;
+    ix.n_edges = d->n_edges;
+    ix.seq_fwd.assign(d->seq_fwd, d->seq_fwd + d->seq_length);
+    ix.node_start.resize(d->n_nodes + 1);
+    ix.edge_idx.resize(d->n_nodes + 1);
+    ix.edges_to.resize(d->n_nodes + 1);
+    for (uint64_t i = 0; i <= d->n_nodes; i++) {
+        ix.node_start[i] = (uint32_t)d->node_seq_idx[i];
+        ix.edge_idx[i] = (uint32_t)d->node_edge_idx[i];
+        ix.edges_to[i] = (uint32_t)d->node_edges_to[i];
+    }
+    ix.edges.resize(d->n_edges);
+    for (uint64_t i = 0; i < d->n_edges; i++) ix.edges[i] = (uint32_t)d->edges[i];
+
+    // Build the probe table on the host, then copy once.
+    const uint32_t k = d->kmer_length;
+    const uint64_t entries = 1ull << (2 * k);
+    std::vector<uint32_t> table(entries, 0xFFFFFFFFu);
+    std::vector<uint2> pos;
+    pos.reserve(d->n_kmer_pos + d->n_kmers);
+    for (uint64_t g = 0; g < d->n_kmers; g++) {
+        const char *key = d->kmer_keys + g * k;
+        uint64_t packed = 0;
+        bool acgt = true;
+        for (uint32_t t = 0; t < k; t++) {
+            int c = vga_base_code(key[t]);
+            if (c < 0) { acgt = false; break; }
+            packed = (packed << 2) | (uint64_t)c;
+        }
+        if (!acgt) {
+            vga_index_release(ctx->index);
+            return vga_set_error(ctx, VGA_ERR_UNSUPPORTED,
+                                 "k-mer %llu of the index holds a base outside upper-case A/C/G/T; the 2-bit probe "
+                                 "table cannot represent it",
+                                 (unsigned long long)g);
+        }
+        uint64_t s = d->kmer_starts[g];
+        if (s >= d->n_kmer_pos) { vga_index_release(ctx->index); return vga_set_error(ctx, VGA_ERR_ARG, "kmer_starts out of range"); }
+        size_t header = pos.size();
+        pos.push_back(make_uint2(0u, 0u));
+        uint32_t cnt = 0;
+        for (uint64_t e = s; e < d->n_kmer_pos; e++) {
+            const vga_kmerpos &p = d->kmer_pos_table[e];
+            if (p.start_orient == 1 && p.end_orient == 1 && p.start == UINT64_MAX && p.end == UINT64_MAX) break;
+            // src/chain.rs:154: only forward/forward records become anchors (map.rs:62)
+            if (p.start_orient == 0 && p.end_orient == 0) {
+                pos.push_back(make_uint2((uint32_t)p.start, (uint32_t)p.end));
+                cnt++;
+            }
+        }
+        if (cnt == 0) {
+            pos.pop_back();  // k-mer only on the reverse strand: a forward-only probe misses
+            continue;
+        }
+        pos[header].x = cnt;
+        if (pos.size() >= 0xFFFFFFFFull) { vga_index_release(ctx->index); return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "position table too large"); }
+        table[packed] = (uint32_t)header;
+    }
+    if (pos.empty()) pos.push_back(make_uint2(0u, 0u));
+    ix.table_entries = entries;
+    ix.n_pos_words = pos.size();
+    VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_table, entries * sizeof(uint32_t)));
+    VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_pos, pos.size() * sizeof(uint2)));
+    VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_table, table.data(), entries * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_pos, pos.data(), pos.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    VGA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    ix.loaded = true;
+    return VGA_OK;
+}
+
+// ---------------------------------------------------------------- read batches
+extern "C" int vga_batch_create(vga_ctx *ctx, const char *reads_concat, const uint64_t *read_off, uint64_t n_reads,
+                                vga_batch **out)
+{
+    if (!ctx || !out || !read_off || (!reads_concat && n_reads && read_off[n_reads])) return VGA_ERR_ARG;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    for (uint64_t i = 0; i < n_reads; i++)
+        if (read_off[i + 1] < read_off[i]) return vga_set_error(ctx, VGA_ERR_ARG, "read_off not monotone at %llu", (unsigned long long)i);
+    vga_batch *b = new vga_batch();
+    b->ctx = ctx;
+    b->n_reads = n_reads;
+    b->total_bases = n_reads ? read_off[n_reads] - read_off[0] : 0;
+    b->read_off.resize(n_reads + 1);
+    uint64_t base = n_reads ? read_off[0] : 0;
+    for (uint64_t i = 0; i <= n_reads; i++) b->read_off[i] = (n_reads ? read_off[i] : 0) - base;
+    b->reads.assign(reads_concat + base, reads_concat + base + b->total_bases);
+    hipError_t e = hipMalloc((void **)&b->d_reads, b->total_bases + 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->d_read_off, (n_reads + 1) * sizeof(uint64_t));
+    if (e == hipSuccess && b->total_bases)
+        e = hipMemcpyAsync(b->d_reads, b->reads.data(), b->total_bases, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(b->d_read_off, b->read_off.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        vga_batch_destroy(b);
+        return vga_set_error(ctx, VGA_ERR_HIP, "vga_batch_create: %s", hipGetErrorString(e));
+    }
+    *out = b;
+    return VGA_OK;
+}
+
+extern "C" void vga_batch_destroy(vga_batch *b)
+{
+    if (!b) return;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    if (b->d_reads) (void)hipFree(b->d_reads);
+    if (b->d_read_off) (void)hipFree(b->d_read_off);
+    delete b;
+}
+
+extern "C" void vga_map_default_params(vga_map_params *p)
+{
+    p->bandwidth = 50;
+    p->max_gap = 1000;
+    p->chain_min_n_anchors = 3;
+    p->only_forward = 1;
+}
+
+extern "C" void vga_poa_default_params(vga_poa_params *p)
+{
+    p->match = 2;
+    p->mismatch = 4;
+    p->gap_open1 = 4;
+    p->gap_ext1 = 2;
+    p->gap_open2 = 24;
+    p->gap_ext2 = 1;
+    p->wb = 10;
+    p->wf = 0.01;
+}

@@ -1,0 +1,551 @@
+// vga_map.hip -- anchors + chaining on gfx950.
+//
+//   K1  k_kmer_probe<false/true>  split_into_kmers + find_positions_for_query_kmer + the forward
+//                                 filter and id assignment of anchors_for_query
+//                                 (src/io.rs:41-56, src/index.rs:309-382, src/chain.rs:134-173)
+//   K2  k_anchor_sort             the stable sort of chain_anchors (src/chain.rs:386-389)
+//   K3  k_chain                   the windowed DP (src/chain.rs:398-450, score_anchor 274-368) and
+//                                 the backtracking into chains (src/chain.rs:455-558)
+//
+// All of it is integer / f64 latency-bound work on a few hundred KB per read; it is laid out so
+// that every global access is coalesced or a wave-uniform broadcast, with one block (K1, K2) or one
+// wavefront (K3) per read.  Wave width is 64 throughout.
+//
+// f64 parity (chain scores must match the CPU bit for bit): the gap cost
+// 0.01*k*g + 0.5*log2(g) is tabulated on the host with the host libm for g in [0, max_gap]
+// (g is an integer, src/chain.rs:338-344), and the remaining + - * round / are IEEE operations
+// evaluated in the reference's order; this file is compiled with -ffp-contract=off.
+#include "vga_common.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#define VGA_WAVE 64
+#define VGA_PROBE_NT 256
+#define VGA_SORT_NT 256
+#define VGA_NONE32 0xFFFFFFFFu
+
+// ------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ uint32_t vga_lane() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t vga_wave_incl_scan(uint32_t v)
+{
+    uint32_t lane = vga_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+
+// block-wide exclusive scan for 256 threads; returns the exclusive prefix and the block total.
+// `ws` must hold 4 words; two barriers.
+__device__ __forceinline__ uint32_t vga_block_excl_scan_256(uint32_t v, uint32_t *ws, uint32_t &total)
+{
+    uint32_t incl = vga_wave_incl_scan(v);
+    uint32_t w = threadIdx.x >> 6;
+    if (vga_lane() == 63) ws[w] = incl;
+    __syncthreads();
+    uint32_t w0 = ws[0], w1 = ws[1], w2 = ws[2], w3 = ws[3];
+    uint32_t before = (w > 0 ? w0 : 0) + (w > 1 ? w1 : 0) + (w > 2 ? w2 : 0);
+    total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return before + incl - v;
+}
+
+__device__ __forceinline__ uint32_t vga_base_code_dev(uint8_t c)
+{
+    // upper-case A/C/G/T -> 0..3, everything else 4 (a query k-mer holding it misses the table,
+    // exactly as its string would miss the reference's k-mer set)
+    return c == 'A' ? 0u : (c == 'C' ? 1u : (c == 'G' ? 2u : (c == 'T' ? 3u : 4u)));
+}
+
+// ------------------------------------------------------------------------------------------ K1
+// One block per read.  Pass 1 (EMIT=false) counts the anchors of each read; pass 2 (EMIT=true)
+// writes them at anchor_off[r] in (query position, table order) order, which is the order
+// anchors_for_query assigns ids in (src/chain.rs:146-166): anchor id == index within the read.
+template <bool EMIT>
+__global__ __launch_bounds__(VGA_PROBE_NT) void k_kmer_probe(
+    const char *__restrict__ reads, const uint64_t *__restrict__ read_off, uint32_t k,
+    const uint32_t *__restrict__ table, const uint2 *__restrict__ pos, uint32_t *__restrict__ cnt_out,
+    const uint64_t *__restrict__ anchor_off, uint32_t *__restrict__ a_qb, uint32_t *__restrict__ a_tb,
+    uint32_t *__restrict__ a_te, uint32_t *__restrict__ a_idx)
+{
+    __shared__ uint8_t codes[VGA_PROBE_NT + 32];
+    __shared__ uint32_t ws[4];
+    const uint32_t r = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t off = read_off[r];
+    const uint64_t L = read_off[r + 1] - off;
+    if (L < k) {  // src/io.rs:47: no k-mers
+        if (!EMIT && tid == 0) cnt_out[r] = 0;
+        return;
+    }
+    const uint64_t nk = L - k + 1;
+    const uint64_t abase = EMIT ? anchor_off[r] : 0;
+    uint32_t running = 0;
+    for (uint64_t c0 = 0; c0 < nk; c0 += VGA_PROBE_NT) {
+        for (uint32_t t = tid; t < VGA_PROBE_NT + k - 1; t += VGA_PROBE_NT) {
+            uint64_t p = c0 + t;
+            codes[t] = p < L ? (uint8_t)vga_base_code_dev((uint8_t)reads[off + p]) : (uint8_t)4;
+        }
+        __syncthreads();
+        const uint64_t i = c0 + tid;
+        uint32_t cnt = 0, hdr = VGA_NONE32;
+        if (i < nk) {
+            uint32_t key = 0, bad = 0;
+            for (uint32_t t = 0; t < k; t++) {
+                uint32_t c = codes[tid + t];
+                bad |= c >> 2;
+                key = (key << 2) | (c & 3u);
+            }
+            if (!bad) {
+                hdr = table[key];
+                if (hdr != VGA_NONE32) cnt = pos[hdr].x;
+            }
+        }
+        uint32_t total;
+        uint32_t excl = vga_block_excl_scan_256(cnt, ws, total);  // two barriers: also protects `codes`
+        if (EMIT && cnt) {
+            uint64_t o = abase + running + excl;
+            for (uint32_t t = 0; t < cnt; t++) {
+                uint2 rec = pos[hdr + 1 + t];
+                a_qb[o + t] = (uint32_t)i;
+                a_tb[o + t] = rec.x;
+                a_te[o + t] = rec.y;
+                a_idx[o + t] = running + excl + t;
+            }
+        }
+        running += total;
+    }
+    if (!EMIT && tid == 0) cnt_out[r] = running;
+}
+
+// ------------------------------------------------------------------------------------------ K2
+// One block per read: stable LSD radix sort (8-bit digits) of (key = target_end, value = anchor id)
+// through global ping-pong buffers.  Stability + ascending original ids reproduce Vec::sort_by.
+__global__ __launch_bounds__(VGA_SORT_NT) void k_anchor_sort(const uint64_t *__restrict__ anchor_off,
+                                                             uint32_t n_pass, uint32_t *key_a, uint32_t *val_a,
+                                                             uint32_t *key_b, uint32_t *val_b)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t base[256];
+    __shared__ uint32_t wave_cnt[4][256];
+    __shared__ uint32_t ws[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint64_t a0 = anchor_off[blockIdx.x];
+    const uint32_t A = (uint32_t)(anchor_off[blockIdx.x + 1] - a0);
+    if (A < 2) {
+        // nothing to move; make the buffer the host will read (a or b by pass parity) valid
+        if ((n_pass & 1u) && A == 1 && tid == 0) { key_b[a0] = key_a[a0]; val_b[a0] = val_a[a0]; }
+        return;
+    }
+    uint32_t *kin = key_a + a0, *vin = val_a + a0, *kout = key_b + a0, *vout = val_b + a0;
+    for (uint32_t pass = 0; pass < n_pass; pass++) {
+        const uint32_t shift = pass * 8;
+        hist[tid] = 0;
+        for (int q = 0; q < 4; q++) wave_cnt[q][tid] = 0;
+        __syncthreads();
+        for (uint32_t e = tid; e < A; e += VGA_SORT_NT) atomicAdd(&hist[(kin[e] >> shift) & 255u], 1u);
+        __syncthreads();
+        uint32_t total;
+        uint32_t ex = vga_block_excl_scan_256(hist[tid], ws, total);
+        base[tid] = ex;
+        __syncthreads();
+        for (uint32_t t0 = 0; t0 < A; t0 += VGA_SORT_NT) {
+            const uint32_t e = t0 + tid;
+            const bool valid = e < A;
+            uint32_t key = 0, val = 0, d = 0;
+            if (valid) { key = kin[e]; val = vin[e]; d = (key >> shift) & 255u; }
+            // lanes of this wave holding the same digit
+            uint64_t m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                uint64_t bal = __ballot((d >> b) & 1u);
+                m &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const uint32_t rank = __popcll(m & lt);
+            if (valid && rank == 0) wave_cnt[w][d] = __popcll(m);
+            __syncthreads();
+            if (valid) {
+                uint32_t o = base[d] + rank;
+                for (uint32_t q = 0; q < w; q++) o += wave_cnt[q][d];
+                kout[o] = key;
+                vout[o] = val;
+            }
+            __syncthreads();
+            base[tid] += wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
+            for (int q = 0; q < 4; q++) wave_cnt[q][tid] = 0;
+            __syncthreads();
+        }
+        __threadfence_block();
+        __syncthreads();
+        uint32_t *t;
+        t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+}
+
+// one block per read: gather sorted fields (perm holds read-local anchor ids)
+__global__ __launch_bounds__(256) void k_anchor_gather_seg(const uint64_t *__restrict__ anchor_off,
+                                                           const uint32_t *__restrict__ perm,
+                                                           const uint32_t *__restrict__ a_qb,
+                                                           const uint32_t *__restrict__ a_tb,
+                                                           const uint32_t *__restrict__ a_te,
+                                                           uint32_t *__restrict__ s_qb, uint32_t *__restrict__ s_tb,
+                                                           uint32_t *__restrict__ s_te)
+{
+    const uint64_t a0 = anchor_off[blockIdx.x];
+    const uint32_t A = (uint32_t)(anchor_off[blockIdx.x + 1] - a0);
+    for (uint32_t i = threadIdx.x; i < A; i += blockDim.x) {
+        uint32_t p = perm[a0 + i];
+        s_qb[a0 + i] = a_qb[a0 + p];
+        s_tb[a0 + i] = a_tb[a0 + p];
+        s_te[a0 + i] = a_te[a0 + p];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K3
+// One wavefront per read.  Lane l keeps the most recent sorted anchor j with j % 64 == l in
+// registers, so the look-back window (bandwidth <= 64) is always register-resident; each step
+// scores anchor i against the whole window at once and reduces with a 64-lane butterfly.
+// Tie rule: the reference scans j from i-1 downwards with a strict '>' (src/chain.rs:417,430), so
+// among equal proposed scores the largest j wins.
+__device__ __forceinline__ void vga_argmax_step(double &p, int &j, int d)
+{
+    double op = __shfl_xor(p, d, 64);
+    int oj = __shfl_xor(j, d, 64);
+    if (op > p || (op == p && oj > j)) { p = op; j = oj; }
+}
+
+__global__ __launch_bounds__(VGA_WAVE) void k_chain(
+    const uint64_t *__restrict__ anchor_off, const uint32_t *__restrict__ s_id, const uint32_t *__restrict__ s_qb,
+    const uint32_t *__restrict__ s_tb, const uint32_t *__restrict__ s_te, uint32_t k, uint32_t bandwidth,
+    uint64_t max_gap, uint32_t min_anchors, const double *__restrict__ gap_cost, double *__restrict__ f_out,
+    int32_t *__restrict__ pred_id_out, int32_t *pred_pos, double *__restrict__ curr_max_out,
+    uint32_t *__restrict__ chain_buf, uint32_t *__restrict__ chain_cnt, uint32_t *__restrict__ chain_words)
+{
+    const uint32_t r = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t a0 = anchor_off[r];
+    const uint32_t A = (uint32_t)(anchor_off[r + 1] - a0);
+    const double kd = (double)k;
+    double curr_max = 0.0;
+
+    double f_l = 0.0;
+    uint32_t qb_l = 0, tb_l = 0, te_l = 0;
+    int j_l = -1;
+
+    for (uint32_t i = 0; i < A; i++) {
+        const uint32_t qbi = s_qb[a0 + i], tbi = s_tb[a0 + i], tei = s_te[a0 + i];  // wave-uniform
+        double p = -1.7976931348623157e308;  // -f64::MAX
+        int j = -1;
+        if (i > 0) {
+            const int min_j = (bandwidth > i) ? 0 : (int)(i - bandwidth);  // src/chain.rs:404-407
+            if (j_l >= min_j) {
+                // score_anchor(a = j_l, b = i), src/chain.rs:274-368, all orientations Forward
+                if (!(qb_l >= qbi || te_l >= tei)) {
+                    const uint64_t ql = (uint64_t)(qbi - qb_l);
+                    const uint64_t tbd = tbi > tb_l ? (uint64_t)(tbi - tb_l) : (uint64_t)(tb_l - tbi);
+                    const uint64_t ted = (uint64_t)(tei - te_l);
+                    const uint64_t tl = tbd < ted ? tbd : ted;
+                    const uint64_t g = ql > tl ? ql - tl : tl - ql;
+                    if (g <= max_gap) {
+                        const double gc = gap_cost[g];
+                        uint64_t ml = ql < tl ? ql : tl;
+                        if ((uint64_t)k < ml) ml = k;
+                        double s = f_l + (double)ml;
+                        s = s - gc;
+                        s = s * 1000.0;
+                        s = round(s);
+                        s = s / 1000.0;
+                        s = s + 0.0;
+                        p = s;
+                        j = j_l;
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) vga_argmax_step(p, j, d);
+        }
+        double fi = kd;  // src/chain.rs:163: initial f(i) = k
+        int pj = -1;
+        if (p > fi) { fi = p; pj = j; }
+        if (p > curr_max) curr_max = p;
+        if (lane == (i & 63u)) { f_l = fi; qb_l = qbi; tb_l = tbi; te_l = tei; j_l = (int)i; }
+        if (lane == 0) {
+            f_out[a0 + i] = fi;
+            pred_pos[a0 + i] = pj;
+            pred_id_out[a0 + i] = pj >= 0 ? (int32_t)s_id[a0 + pj] : -1;
+        }
+    }
+    if (lane == 0) curr_max_out[r] = curr_max;
+    __threadfence_block();
+
+    // ---- backtracking, src/chain.rs:455-558.  Chains are emitted in discovery order (highest sorted
+    // index first), members in walk order (descending); the host reverses each chain.
+    uint32_t *buf = chain_buf + 3 * a0 + 2 * (uint64_t)r;
+    volatile int32_t *vpred = pred_pos + a0;
+    const double *fr = f_out + a0;
+    uint32_t nch = 0, wpos = 0;
+    for (int top = (int)A; top > 0; top -= 64) {
+        const int i = top - 1 - (int)lane;
+        bool cand = false;
+        if (i >= 0) cand = vpred[i] >= 0 && fr[i] == curr_max;
+        uint64_t mask = __ballot(cand);
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            int cur = top - 1 - l;
+            if (vpred[cur] < 0) continue;  // consumed by an earlier chain (src/chain.rs:469,478)
+            const uint32_t hdr = wpos++;
+            uint32_t len = 0;
+            int pnext;
+            while ((pnext = vpred[cur]) >= 0) {
+                if (lane == 0) { vpred[cur] = -1; buf[wpos] = (uint32_t)cur; }
+                __threadfence_block();
+                wpos++;
+                len++;
+                cur = pnext;
+            }
+            if (lane == 0) buf[wpos] = (uint32_t)cur;
+            wpos++;
+            len++;
+            if (len >= min_anchors) {
+                if (lane == 0) buf[hdr] = len;
+                nch++;
+            } else {
+                wpos = hdr;
+            }
+        }
+    }
+    if (lane == 0) { chain_cnt[r] = nch; chain_words[r] = wpos; }
+}
+
+// ------------------------------------------------------------------------------------------ host
+namespace {
+
+struct map_ws {
+    vga_dbuf<uint32_t> cnt;
+    vga_dbuf<uint64_t> anchor_off;
+    vga_dbuf<uint32_t> a_qb, a_tb, a_te, a_idx, key_b, val_b, s_qb, s_tb, s_te;
+    vga_dbuf<double> f, curr_max, gap_cost;
+    vga_dbuf<int32_t> pred_id, pred_pos;
+    vga_dbuf<uint32_t> chain_buf, chain_cnt, chain_words;
+};
+
+template <typename T>
+T *xmalloc(size_t n)
+{
+    return (T *)malloc((n ? n : 1) * sizeof(T));
+}
+
+}  // namespace
+
+extern "C" void vga_map_result_free(vga_map_result *r)
+{
+    if (!r) return;
+    free(r->anchor_off);
+    free(r->anchor_id);
+    free(r->query_begin);
+    free(r->target_begin);
+    free(r->target_end);
+    free(r->max_chain_score);
+    free(r->best_pred_id);
+    free(r->curr_max);
+    free(r->chain_off);
+    free(r->chain_placeholder);
+    free(r->chain_anchor_off);
+    free(r->chain_anchor_idx);
+    free(r);
+}
+
+extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map_result **out)
+{
+    if (!b || !params || !out) return VGA_ERR_ARG;
+    vga_ctx *ctx = b->ctx;
+    *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    if (!ctx->index.loaded) return vga_set_error(ctx, VGA_ERR_NO_INDEX, "vga_map_batch: no index uploaded");
+    if (!params->only_forward)
+        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "only_forward=0 (reverse-strand anchors) is not supported yet");
+    if (params->bandwidth == 0 || params->bandwidth > 64)
+        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "bandwidth %u: the wavefront chaining kernel supports 1..64", params->bandwidth);
+    if (params->max_gap > (1u << 22))
+        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "max_gap too large for the tabulated gap cost");
+    const vga_dev_index &ix = ctx->index;
+    const uint64_t R = b->n_reads;
+    hipStream_t st = ctx->stream;
+    map_ws ws;
+    vga_timers_reset(ctx);
+    auto t_host0 = std::chrono::steady_clock::now();
+
+    vga_map_result *res = (vga_map_result *)calloc(1, sizeof(vga_map_result));
+    res->n_reads = R;
+    res->anchor_off = xmalloc<uint64_t>(R + 1);
+    res->curr_max = xmalloc<double>(R);
+    res->chain_off = xmalloc<uint64_t>(R + 1);
+    res->anchor_off[0] = 0;
+    res->chain_off[0] = 0;
+    if (R == 0) {
+        res->chain_anchor_off = xmalloc<uint64_t>(1);
+        res->chain_anchor_off[0] = 0;
+        *out = res;
+        return VGA_OK;
+    }
+
+#define MAP_CHECK(call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            vga_map_result_free(res);                                                                \
+            return vga_set_error(ctx, VGA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                                 __LINE__);                                                          \
+        }                                                                                            \
+    } while (0)
+
+    // ---- K1 pass 1: count
+    MAP_CHECK(ws.cnt.reserve(R));
+    MAP_CHECK(ws.anchor_off.reserve(R + 1));
+    int t_total = vga_timer_begin(ctx, "map_total", 0);
+    int t1 = vga_timer_begin(ctx, "kmer_probe_count", 0);
+    hipLaunchKernelGGL(k_kmer_probe<false>, dim3((unsigned)R), dim3(VGA_PROBE_NT), 0, st, b->d_reads, b->d_read_off, ix.k,
+                       ix.d_table, ix.d_pos, ws.cnt.p, (const uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                       (uint32_t *)nullptr, (uint32_t *)nullptr);
+    vga_timer_end(ctx, t1);
+    std::vector<uint32_t> h_cnt(R);
+    MAP_CHECK(hipMemcpyAsync(h_cnt.data(), ws.cnt.p, R * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    MAP_CHECK(hipStreamSynchronize(st));
+    uint64_t total = 0;
+    for (uint64_t r = 0; r < R; r++) {
+        res->anchor_off[r] = total;
+        total += h_cnt[r];
+    }
+    res->anchor_off[R] = total;
+    res->n_anchors = total;
+    res->n_hits = total;
+    MAP_CHECK(hipMemcpyAsync(ws.anchor_off.p, res->anchor_off, (R + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+
+    const size_t An = (size_t)total;
+    MAP_CHECK(ws.a_qb.reserve(An)); MAP_CHECK(ws.a_tb.reserve(An)); MAP_CHECK(ws.a_te.reserve(An));
+    MAP_CHECK(ws.a_idx.reserve(An)); MAP_CHECK(ws.key_b.reserve(An)); MAP_CHECK(ws.val_b.reserve(An));
+    MAP_CHECK(ws.s_qb.reserve(An)); MAP_CHECK(ws.s_tb.reserve(An)); MAP_CHECK(ws.s_te.reserve(An));
+    MAP_CHECK(ws.f.reserve(An)); MAP_CHECK(ws.pred_id.reserve(An)); MAP_CHECK(ws.pred_pos.reserve(An));
+    MAP_CHECK(ws.curr_max.reserve(R));
+    MAP_CHECK(ws.chain_buf.reserve(3 * An + 2 * R + 2));
+    MAP_CHECK(ws.chain_cnt.reserve(R)); MAP_CHECK(ws.chain_words.reserve(R));
+
+    // gap cost table (src/chain.rs:348-354), host libm
+    const uint64_t mg = params->max_gap;
+    std::vector<double> gc(mg + 1);
+    gc[0] = 0.0;
+    for (uint64_t g = 1; g <= mg; g++) gc[g] = 0.01 * (double)ix.k * (double)g + 0.5 * log2((double)g);
+    MAP_CHECK(ws.gap_cost.reserve(mg + 1));
+    MAP_CHECK(hipMemcpyAsync(ws.gap_cost.p, gc.data(), (mg + 1) * sizeof(double), hipMemcpyHostToDevice, st));
+
+    // ---- K1 pass 2: emit
+    // byte model B_map: L + 4(L-k+1) read+table, 8H positions, 16A anchor write
+    uint64_t nkm = 0;
+    for (uint64_t r = 0; r < R; r++) {
+        uint64_t L = b->read_off[r + 1] - b->read_off[r];
+        if (L >= ix.k) nkm += L - ix.k + 1;
+    }
+    int t2 = vga_timer_begin(ctx, "kmer_probe_emit", b->total_bases + 4 * nkm + 8 * total + 16 * total);
+    hipLaunchKernelGGL(k_kmer_probe<true>, dim3((unsigned)R), dim3(VGA_PROBE_NT), 0, st, b->d_reads, b->d_read_off, ix.k,
+                       ix.d_table, ix.d_pos, (uint32_t *)nullptr, ws.anchor_off.p, ws.a_qb.p, ws.a_tb.p, ws.a_te.p, ws.a_idx.p);
+    vga_timer_end(ctx, t2);
+
+    // ---- K2: sort by target_end
+    uint32_t nbits = 1;
+    while ((1ull << nbits) <= ix.seq_length && nbits < 32) nbits++;
+    const uint32_t n_pass = (nbits + 7) / 8;
+    // the keys are sorted in place of a_te (ping) / key_b (pong); the original te is re-gathered from a copy
+    vga_dbuf<uint32_t> key_a;
+    MAP_CHECK(key_a.reserve(An));
+    if (An) MAP_CHECK(hipMemcpyAsync(key_a.p, ws.a_te.p, An * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    int t3 = vga_timer_begin(ctx, "anchor_sort", (uint64_t)n_pass * 16 * total + 24 * total);
+    hipLaunchKernelGGL(k_anchor_sort, dim3((unsigned)R), dim3(VGA_SORT_NT), 0, st, ws.anchor_off.p, n_pass, key_a.p,
+                       ws.a_idx.p, ws.key_b.p, ws.val_b.p);
+    const uint32_t *perm = (n_pass & 1u) ? ws.val_b.p : ws.a_idx.p;
+    hipLaunchKernelGGL(k_anchor_gather_seg, dim3((unsigned)R), dim3(256), 0, st, ws.anchor_off.p, perm, ws.a_qb.p, ws.a_tb.p,
+                       ws.a_te.p, ws.s_qb.p, ws.s_tb.p, ws.s_te.p);
+    vga_timer_end(ctx, t3);
+
+    // ---- K3: chain DP + backtracking
+    int t4 = vga_timer_begin(ctx, "chain_dp", 16 * total + 12 * total);
+    hipLaunchKernelGGL(k_chain, dim3((unsigned)R), dim3(VGA_WAVE), 0, st, ws.anchor_off.p, perm, ws.s_qb.p, ws.s_tb.p, ws.s_te.p,
+                       ix.k, params->bandwidth, params->max_gap, params->chain_min_n_anchors, ws.gap_cost.p, ws.f.p,
+                       ws.pred_id.p, ws.pred_pos.p, ws.curr_max.p, ws.chain_buf.p, ws.chain_cnt.p, ws.chain_words.p);
+    vga_timer_end(ctx, t4);
+    vga_timer_end(ctx, t_total);
+
+    // ---- results to host
+    res->anchor_id = xmalloc<uint32_t>(An);
+    res->query_begin = xmalloc<uint32_t>(An);
+    res->target_begin = xmalloc<uint32_t>(An);
+    res->target_end = xmalloc<uint32_t>(An);
+    res->max_chain_score = xmalloc<double>(An);
+    res->best_pred_id = xmalloc<int32_t>(An);
+    std::vector<uint32_t> h_chain_cnt(R), h_chain_words(R);
+    std::vector<uint32_t> h_chain_buf(3 * An + 2 * R + 2);
+    if (An) {
+        MAP_CHECK(hipMemcpyAsync(res->anchor_id, perm, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(res->query_begin, ws.s_qb.p, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(res->target_begin, ws.s_tb.p, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(res->target_end, ws.s_te.p, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(res->max_chain_score, ws.f.p, An * 8, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(res->best_pred_id, ws.pred_id.p, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(h_chain_buf.data(), ws.chain_buf.p, (3 * An + 2 * R) * 4, hipMemcpyDeviceToHost, st));
+    }
+    MAP_CHECK(hipMemcpyAsync(res->curr_max, ws.curr_max.p, R * 8, hipMemcpyDeviceToHost, st));
+    MAP_CHECK(hipMemcpyAsync(h_chain_cnt.data(), ws.chain_cnt.p, R * 4, hipMemcpyDeviceToHost, st));
+    MAP_CHECK(hipMemcpyAsync(h_chain_words.data(), ws.chain_words.p, R * 4, hipMemcpyDeviceToHost, st));
+    MAP_CHECK(hipStreamSynchronize(st));
+    vga_timers_collect(ctx);
+
+    // ---- chains: discovery order per read, members reversed to ascending (src/chain.rs:546);
+    // a read without chains gets one placeholder (src/chain.rs:644-649)
+    uint64_t n_chains = 0, n_members = 0;
+    for (uint64_t r = 0; r < R; r++) {
+        uint32_t c = h_chain_cnt[r];
+        n_chains += c ? c : 1;
+        n_members += h_chain_words[r] - c;
+    }
+    res->n_chains = n_chains;
+    res->chain_placeholder = xmalloc<uint8_t>(n_chains);
+    res->chain_anchor_off = xmalloc<uint64_t>(n_chains + 1);
+    res->chain_anchor_idx = xmalloc<uint32_t>(n_members);
+    uint64_t ci = 0, mi = 0;
+    for (uint64_t r = 0; r < R; r++) {
+        res->chain_off[r] = ci;
+        const uint32_t *buf = h_chain_buf.data() + 3 * res->anchor_off[r] + 2 * r;
+        uint32_t c = h_chain_cnt[r], wp = 0;
+        if (c == 0) {
+            res->chain_placeholder[ci] = 1;
+            res->chain_anchor_off[ci] = mi;
+            ci++;
+            continue;
+        }
+        for (uint32_t q = 0; q < c; q++) {
+            uint32_t len = buf[wp++];
+            res->chain_placeholder[ci] = 0;
+            res->chain_anchor_off[ci] = mi;
+            for (uint32_t t = 0; t < len; t++) res->chain_anchor_idx[mi + t] = buf[wp + len - 1 - t];
+            wp += len;
+            mi += len;
+            ci++;
+        }
+    }
+    res->chain_off[R] = ci;
+    res->chain_anchor_off[ci] = mi;
+    res->ms_probe = vga_timer_sum(ctx, "kmer_probe");
+    res->ms_sort = vga_timer_sum(ctx, "anchor_sort");
+    res->ms_chain = vga_timer_sum(ctx, "chain_dp");
+    res->ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+#undef MAP_CHECK
+    *out = res;
+    return VGA_OK;
+}

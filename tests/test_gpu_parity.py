@@ -1,0 +1,219 @@
+"""GPU parity tests: every call goes through the C ABI of libvga_hip.so and is compared with the CPU
+oracle on the same inputs -- bit-exact for anchors, sort order, f(i) (f64 bit patterns), predecessors,
+chain membership, POA score / CIGAR / cs / node path."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from helpers import DATA, compare_map, pkg, run_smoke, upload_oracle_index
+
+pytestmark = pytest.mark.gpu
+
+DRB1 = os.path.join(DATA, "DRB1-3123.gfa")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    p = pkg()
+    c = p.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def drb1(oracle):
+    g = oracle.Graph.from_gfa(DRB1)
+    return g, oracle.Index(g, 11)
+
+
+def simple_graph(o):
+    return o.Graph.from_nodes_edges([(1, "A"), (2, "CT"), (3, "GA"), (4, "GCA")], [(1, 2), (1, 3), (2, 4), (3, 4)])
+
+
+def test_smoke():
+    run_smoke()
+
+
+def test_anchor_vectors_of_the_reference(oracle, ctx):
+    """src/chain.rs:742-777 anchors_found / anchors_found_2 through the device probe"""
+    ix = oracle.Index(simple_graph(oracle), 3)
+    upload_oracle_index(ctx, ix)
+    seqs = ["ACTGCA", "AGAGC", "AAATTT", "", "AC"]
+    mo = ctx.batch(seqs).map(pkg().default_map_params())
+    counts = np.diff(mo.anchor_off).tolist()
+    assert counts == [4, 3, 0, 0, 0]
+    p = pkg().default_map_params()
+    p.chain_min_n_anchors = 1
+    compare_map(oracle, ix, ctx.batch(seqs).map(p), seqs, min_anchors=1)
+    g2 = oracle.Graph.from_nodes_edges([(1, "AAAAAAAAAAA"), (2, "C"), (3, "G"), (4, "TTTTTTTTTTTT")],
+                                       [(1, 2), (1, 3), (2, 4), (3, 4)])
+    ix2 = oracle.Index(g2, 11)
+    upload_oracle_index(ctx, ix2)
+    mo2 = ctx.batch(["AAAAACTTTTTT"]).map()
+    assert int(mo2.n_anchors) == 2
+    compare_map(oracle, ix2, mo2, ["AAAAACTTTTTT"])
+
+
+def test_map_config1_placeholder(oracle, ctx):
+    """BASELINE config #1: test.gfa + single-read-test.fa, k=11 -> one placeholder chain"""
+    g = oracle.Graph.from_gfa(os.path.join(DATA, "test.gfa"))
+    ix = oracle.Index(g, 11)
+    upload_oracle_index(ctx, ix)
+    reads = oracle.read_seqs_from_file(os.path.join(DATA, "single-read-test.fa"))
+    b = ctx.batch([r[1] for r in reads])
+    mo = b.map()
+    assert mo.chains_of(0) == [(True, [])]
+    al = b.align(mo)
+    assert al.aligned.tolist() == [0]
+    # the whole linearisation as a read does chain (src/chain.rs:946-976 test_chains_2)
+    p = pkg().default_map_params()
+    p.chain_min_n_anchors = 2
+    compare_map(oracle, ix, ctx.batch([ix.seq_fwd]).map(p), [ix.seq_fwd], min_anchors=2)
+
+
+def test_map_config2_sample(oracle, ctx, drb1):
+    """BASELINE config #2 (sample): 150 bp reads, 1 % substitutions, map-only"""
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    reads = pkg().readsim.config2_reads(DRB1, 300)
+    seqs = [r.seq for r in reads]
+    compare_map(oracle, ix, ctx.batch(seqs).map(), seqs)
+
+
+def test_map_config3_sample_and_edge_reads(oracle, ctx, drb1):
+    """BASELINE config #3 (sample): 10 kbp ONT-profile reads + ragged / degenerate reads in one batch"""
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    reads = pkg().readsim.config3_reads(DRB1, 12)
+    seqs = [r.seq for r in reads]
+    seqs += ["", "ACGT", "N" * 50, seqs[0][:11], seqs[1][:300].replace("A", "N", 3), "ACGTACGTACGTACGTAAAAAAAAAAAAAAAAAAAAAA"]
+    compare_map(oracle, ix, ctx.batch(seqs).map(), seqs)
+
+
+def test_map_parameters(oracle, ctx, drb1):
+    """non-default bandwidth / max_gap / min_anchors follow the oracle too"""
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    reads = pkg().readsim.simulate_reads(DRB1, 20, 1500, 0.03, 0.03, 0.04, seed=3)
+    seqs = [r.seq for r in reads]
+    for bw, mg, ma in ((10, 50, 2), (64, 5000, 5), (1, 1000, 1)):
+        p = pkg().default_map_params()
+        p.bandwidth, p.max_gap, p.chain_min_n_anchors = bw, mg, ma
+        compare_map(oracle, ix, ctx.batch(seqs).map(p), seqs, bw, mg, ma)
+
+
+def _rand_problem(rng, n_nodes, max_len, qlen_scale=1.0, alphabet="ACGT"):
+    nodes = ["".join(rng.choice(alphabet) for _ in range(rng.randint(1, max_len))) for _ in range(n_nodes)]
+    edges = []
+    for v in range(1, n_nodes):
+        srcs = {v - 1} if rng.random() < 0.8 else set()
+        for _ in range(rng.randint(0, 2)):
+            srcs.add(rng.randint(max(0, v - 6), v - 1))
+        for s in sorted(srcs):
+            edges.append((s, v))
+    # walk a random path to make the query, then mutate it
+    path, v = [], 0
+    out = {}
+    for s, d in edges:
+        out.setdefault(s, []).append(d)
+    while True:
+        path.append(v)
+        if v not in out:
+            break
+        v = rng.choice(out[v])
+    q = "".join(nodes[v] for v in path)
+    q = q[: max(1, int(len(q) * qlen_scale))]
+    ql = list(q)
+    for i in range(len(ql)):
+        x = rng.random()
+        if x < 0.05:
+            ql[i] = rng.choice("ACGT")
+        elif x < 0.08:
+            ql[i] = ql[i] + "".join(rng.choice("ACGT") for _ in range(rng.randint(1, 4)))
+        elif x < 0.11:
+            ql[i] = ""
+    q = "".join(ql) or "A"
+    return nodes, edges, q
+
+
+def _check_poa(oracle, ctx, problems, params=None, oparams=None):
+    out = ctx.poa_batch(problems, params)
+    for i, (nodes, edges, q) in enumerate(problems):
+        ref = oracle.poa_align(nodes, edges, q, oparams)
+        assert bool(out.ok[i]) == ref.ok, f"problem {i}: ok differs"
+        assert int(out.n_rows[i]) == ref.n_rows and int(out.n_cells[i]) == ref.n_cells, f"problem {i}: band cells differ"
+        if not ref.ok:
+            continue
+        assert int(out.best_score[i]) == ref.best_score, f"problem {i}: score {out.best_score[i]} vs {ref.best_score}"
+        assert out.cigar[i] == ref.cigar, f"problem {i}: CIGAR differs"
+        assert out.cs[i] == ref.cs_string, f"problem {i}: cs differs"
+        s, e = int(out.path_off[i]), int(out.path_off[i + 1])
+        assert out.abpoa_nodes[s:e].tolist() == ref.abpoa_nodes
+        assert out.graph_nodes[s:e].tolist() == ref.graph_nodes
+        assert (int(out.aln_start_offset[i]), int(out.aln_end_offset[i]), int(out.n_aligned_bases[i])) == (
+            ref.aln_start_offset, ref.aln_end_offset, ref.n_aligned_bases)
+
+
+def test_poa_random_small_graphs(oracle, ctx):
+    rng = random.Random(1234)
+    problems = [_rand_problem(rng, rng.randint(1, 40), 6) for _ in range(150)]
+    problems += [_rand_problem(rng, rng.randint(20, 120), 12, qlen_scale=s) for s in (0.3, 0.6, 1.0, 1.0) for _ in range(10)]
+    problems += [_rand_problem(rng, 8, 5, alphabet="ACGTN") for _ in range(20)]
+    problems += [(["A"], [], "A"), (["ACGT"], [], "T"), (["A", "C", "G"], [(0, 2), (1, 2)], "CG"),
+                 (["AC", "GT"], [], "ACGTACGT")]
+    _check_poa(oracle, ctx, problems)
+
+
+def test_poa_wide_rows_and_unbanded(oracle, ctx):
+    """rows wider than one 256-lane step, long nodes, and wb < 0 (no banding)"""
+    rng = random.Random(99)
+    problems = [_rand_problem(rng, 60, 60) for _ in range(6)]
+    _check_poa(oracle, ctx, problems)
+    pp, op = pkg().default_poa_params(), oracle.default_poa_params()
+    pp.wb = -1
+    op.wb = -1
+    _check_poa(oracle, ctx, problems[:3] + [_rand_problem(rng, 12, 8) for _ in range(20)], pp, op)
+    pp2, op2 = pkg().default_poa_params(), oracle.default_poa_params()
+    for p_ in (pp2, op2):
+        p_.match, p_.mismatch, p_.gap_open1, p_.gap_ext1, p_.gap_open2, p_.gap_ext2, p_.wb, p_.wf = 1, 3, 2, 2, 10, 1, 3, 0.05
+    _check_poa(oracle, ctx, [_rand_problem(rng, 30, 8) for _ in range(30)], pp2, op2)
+
+
+def _check_align(oracle, ctx, ix, reads):
+    seqs = [r.seq for r in reads]
+    b = ctx.batch(seqs)
+    mo = b.map()
+    compare_map(oracle, ix, mo, seqs)
+    al = b.align(mo)
+    cg, ag, st = oracle.map_reads(ix, [r.name for r in reads], seqs)
+    lines = ag.splitlines()
+    assert len(lines) == len(seqs)
+    for r in range(len(seqs)):
+        f = lines[r].split("\t")
+        if f[5] == "*":
+            assert not al.aligned[r]
+            continue
+        assert al.aligned[r], f"read {r} aligned on the CPU only"
+        hs = al.path_handles[int(al.path_off[r]):int(al.path_off[r + 1])].tolist()
+        assert "".join((">" if not (h & 1) else "<") + str(h >> 1) for h in hs) == f[5], f"read {r}: node path"
+        assert f[12] == "as:i:-30 " + al.cs[r] + ",cg:Z:" + al.cigar[r], f"read {r}: cs / CIGAR"
+        assert (int(f[6]), int(f[7]), int(f[8]), int(f[10])) == (
+            int(al.path_length[r]), int(al.path_start[r]), int(al.path_end[r]), int(al.block_length[r]))
+    assert al.poa_cells == st["poa_cells"] and al.poa_rows == st["poa_rows"]
+    return al
+
+
+def test_align_short_reads(oracle, ctx, drb1):
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    _check_align(oracle, ctx, ix, pkg().readsim.config2_reads(DRB1, 60))
+
+
+def test_align_config3_sample(oracle, ctx, drb1):
+    """BASELINE config #3 (sample): 10 kbp ONT-profile reads, --also-align"""
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    _check_align(oracle, ctx, ix, pkg().readsim.simulate_reads(DRB1, 10, 2500, 0.03, 0.03, 0.04, seed=11))
+    _check_align(oracle, ctx, ix, pkg().readsim.config3_reads(DRB1, 3))
