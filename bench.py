@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X vgaligner hot path (map -> chain -> align).
+
+Workload (BASELINE.json configs[2], the one the metric is quoted on): HLA DRB1-3123 graph, k=11,
+10 000 synthetic 10 kbp ONT-error-profile reads (3 % sub / 3 % ins / 4 % del, PCG64 seed 77),
+`--also-align`.  One "step" = one pass of the whole hot path over the batch: k-mer probe, anchor
+sort, chaining DP + backtracking, subgraph extraction, banded POA DP, traceback, result hand-over.
+Reads are resident in HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Rank 0 prints ONE JSON line.  Multi-GPU: reads shard embarrassingly (every rank maps its own batch of
+the same size against a replicated index; no data-path collective) -> "scaling": "weak".
+The cpu_baseline leg (rank 0, N=1 only) times the single-threaded CPU oracle on a bounded sample of the
+same workload; it is a reported baseline, not the target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+GFA = os.path.join(ROOT, "tests", "golden", "data", "DRB1-3123.gfa")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10000, help="reads per GPU (default: the full config #3 batch)")
+    ap.add_argument("--read-len", type=int, default=10000)
+    ap.add_argument("--cpu-sample", type=int, default=8, help="reads of the workload timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the library has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+
+    pkg = ge.load_package()
+
+    # ---- workload: identical generator on every rank, different seed per rank (different reads, same shape)
+    t0 = time.time()
+    reads = pkg.readsim.simulate_reads(GFA, args.reads, args.read_len, 0.03, 0.03, 0.04, seed=77 + rank)
+    seqs = [r.seq for r in reads]
+    t_gen = time.time() - t0
+
+    # ---- index: built by the product's own C++ host, uploaded once
+    hidx = pkg.HostIndex.build_from_gfa(GFA, 11)
+    ctx = pkg.Context(local_rank)
+    hidx.upload(ctx)
+    batch = ctx.batch(seqs)  # reads are now resident in HBM
+
+    def barrier():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    last = None
+    for _ in range(args.warmup):
+        last = batch.map_align_raw()
+    barrier()
+    t_start = time.perf_counter()
+    kern = {}
+    for _ in range(args.steps):
+        last = batch.map_align_raw()
+        for k in last["kernels"]:
+            e = kern.setdefault(k["name"], {"ms": 0.0, "launches": 0, "bytes": 0})
+            e["ms"] += k["ms"]
+            e["launches"] += k["launches"]
+            e["bytes"] += k["algorithmic_bytes"]
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([last["aligned"], last["n_reads"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        aligned_all, reads_all = float(cnt[0].item()), float(cnt[1].item())
+    else:
+        aligned_all, reads_all = float(last["aligned"]), float(last["n_reads"])
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = aligned_all * args.steps / elapsed
+    # ---- roofline of the dominant kernel (live hipEvent timing on the library's own stream)
+    dom = max((k for k in kern if k.endswith("_dp") or k.endswith("traceback") or k.startswith("kmer") or k.startswith("anchor")),
+              key=lambda k: kern[k]["ms"])
+    d = kern[dom]
+    avg_ms = d["ms"] / max(d["launches"], 1)
+    bytes_per_launch = d["bytes"] / max(d["launches"], 1)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        try:
+            tj = json.load(open(tp))
+            if tj.get("kernel") == dom and tj.get("reads") == args.reads and tj.get("read_len") == args.read_len:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 3),
+                "launches": d["launches"], "algorithmic_bytes_per_launch": int(bytes_per_launch)}
+
+    # ---- CPU baseline: the single-threaded oracle on a bounded sample of the same reads (N=1 only)
+    cpu = None
+    if world == 1 and args.cpu_sample > 0:
+        from oracle import oracle_py as o
+
+        o.build()
+        g = o.Graph.from_gfa(GFA)
+        oix = o.Index(g, 11)
+        ns = min(args.cpu_sample, len(seqs))
+        tc = time.perf_counter()
+        _, ag, st = o.map_reads(oix, [r.name for r in reads[:ns]], seqs[:ns])
+        dt = time.perf_counter() - tc
+        cpu = {"value": round(st["n_aligned_reads"] / dt, 4), "unit": "aligned reads/s", "cores": 1, "kind": "port",
+               "sample": f"first {ns} reads of the workload, oracle/libvga_oracle.so (O(log n) k-mer lookup, no debug printing)",
+               "seconds": round(dt, 2)}
+
+    out = {
+        "metric": "aligned reads/sec (10 kbp ONT vs HLA graph)",
+        "value": round(value, 2),
+        "unit": "aligned reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 2),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32+f64",
+        "data": "synthetic",
+        "config": {"workload": "config3: HLA DRB1-3123 graph, k=11, %d x %d bp ONT-profile reads per GPU, --also-align"
+                               % (args.reads, args.read_len),
+                   "reads_per_gpu": args.reads, "read_len": args.read_len, "sharding": "reads, replicated index, no collective"},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "reads_per_s": round(reads_all * args.steps / elapsed, 2),
+        "per_step": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last.items() if k != "kernels"},
+        "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in kern.items()},
+        "gen_s": round(t_gen, 1),
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

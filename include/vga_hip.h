@@ -160,6 +160,7 @@ typedef struct {
     char *cs;                   /* "cs:Z:..." */
     uint64_t *n_rows;           /* N of the byte model: graph bases in the subgraph */
     uint64_t *n_cells;          /* C of the byte model: sum of band widths */
+    uint64_t *n_value_cells;    /* cells of the rows whose values are kept in HBM (last base of each node) */
     float ms_dp, ms_traceback, ms_total;
 } vga_poa_result;
 void vga_poa_result_free(vga_poa_result *r);
@@ -194,7 +195,7 @@ typedef struct {
     char *cigar;
     uint64_t *cs_off;
     char *cs;
-    uint64_t poa_rows, poa_cells, poa_problems; /* totals for the byte model */
+    uint64_t poa_rows, poa_cells, poa_value_cells, poa_problems; /* totals for the byte model */
     float ms_subgraph, ms_dp, ms_traceback, ms_total;
 } vga_align_result;
 

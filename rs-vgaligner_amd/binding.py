@@ -83,7 +83,7 @@ class PoaResult(C.Structure):
         ("abpoa_nodes", _P(C.c_uint32)), ("graph_nodes", _P(C.c_uint32)), ("aln_start_offset", _P(C.c_uint32)),
         ("aln_end_offset", _P(C.c_uint32)), ("n_aligned_bases", _P(C.c_uint32)), ("cigar_off", _P(C.c_uint64)),
         ("cigar", _P(C.c_char)), ("cs_off", _P(C.c_uint64)), ("cs", _P(C.c_char)), ("n_rows", _P(C.c_uint64)),
-        ("n_cells", _P(C.c_uint64)), ("ms_dp", C.c_float), ("ms_traceback", C.c_float), ("ms_total", C.c_float),
+        ("n_cells", _P(C.c_uint64)), ("n_value_cells", _P(C.c_uint64)), ("ms_dp", C.c_float), ("ms_traceback", C.c_float), ("ms_total", C.c_float),
     ]
 
 
@@ -93,7 +93,7 @@ class AlignResult(C.Structure):
         ("path_length", _P(C.c_uint32)), ("path_start", _P(C.c_uint32)), ("path_end", _P(C.c_uint32)),
         ("block_length", _P(C.c_uint32)), ("best_score", _P(C.c_int32)), ("cigar_off", _P(C.c_uint64)),
         ("cigar", _P(C.c_char)), ("cs_off", _P(C.c_uint64)), ("cs", _P(C.c_char)),
-        ("poa_rows", C.c_uint64), ("poa_cells", C.c_uint64), ("poa_problems", C.c_uint64),
+        ("poa_rows", C.c_uint64), ("poa_cells", C.c_uint64), ("poa_value_cells", C.c_uint64), ("poa_problems", C.c_uint64),
         ("ms_subgraph", C.c_float), ("ms_dp", C.c_float), ("ms_traceback", C.c_float), ("ms_total", C.c_float),
     ]
 
@@ -229,6 +229,7 @@ class PoaOut:
         self.cs = [cs[int(self.cs_off[i]):int(self.cs_off[i + 1]) - 1].decode() for i in range(n)]
         self.n_rows = _np(r.n_rows, n, np.uint64)
         self.n_cells = _np(r.n_cells, n, np.uint64)
+        self.n_value_cells = _np(r.n_value_cells, n, np.uint64)
         self.ms = {"dp": r.ms_dp, "traceback": r.ms_traceback, "total": r.ms_total}
         L.vga_poa_result_free(ptr)
 
@@ -253,6 +254,7 @@ class AlignOut:
         self.cigar = [cig[int(self.cigar_off[i]):int(self.cigar_off[i + 1]) - 1].decode() for i in range(R)]
         self.cs = [cs[int(self.cs_off[i]):int(self.cs_off[i + 1]) - 1].decode() for i in range(R)]
         self.poa_rows, self.poa_cells, self.poa_problems = int(r.poa_rows), int(r.poa_cells), int(r.poa_problems)
+        self.poa_value_cells = int(r.poa_value_cells)
         self.ms = {"subgraph": r.ms_subgraph, "dp": r.ms_dp, "traceback": r.ms_traceback, "total": r.ms_total}
         L.vga_align_result_free(ptr)
 
@@ -284,6 +286,35 @@ class Batch:
         out = _P(AlignResult)()
         self.ctx._check(L.vga_align_batch(self.h, chains._ptr, best_n, C.byref(p), C.byref(out)))
         return AlignOut(L, out)
+
+    def map_align_raw(self, map_params: Optional[MapParams] = None, best_n: int = 1,
+                      poa_params: Optional[PoaParams] = None) -> dict:
+        """One pass of the whole hot path without converting the results to numpy (bench.py's timed step).
+        Returns counters only."""
+        L = self.ctx.L
+        mp = map_params or default_map_params()
+        pp = poa_params or default_poa_params()
+        m = _P(MapResult)()
+        self.ctx._check(L.vga_map_batch(self.h, C.byref(mp), C.byref(m)))
+        kt_map = self.ctx.kernel_times()
+        try:
+            a = _P(AlignResult)()
+            self.ctx._check(L.vga_align_batch(self.h, m, best_n, C.byref(pp), C.byref(a)))
+            kt_aln = self.ctx.kernel_times()
+            r, q = a.contents, m.contents
+            R = int(r.n_reads)
+            aligned = int(np.ctypeslib.as_array(r.aligned, shape=(R,)).sum()) if R else 0
+            out = dict(n_reads=R, aligned=aligned, n_anchors=int(q.n_anchors), n_hits=int(q.n_hits),
+                       poa_rows=int(r.poa_rows), poa_cells=int(r.poa_cells), poa_value_cells=int(r.poa_value_cells),
+                       poa_problems=int(r.poa_problems), path_bases=int(np.ctypeslib.as_array(r.path_length, shape=(R,)).sum()) if R else 0,
+                       cigar_bytes=int(r.cigar_off[R]) if R else 0,
+                       ms_map=float(q.ms_total), ms_probe=float(q.ms_probe), ms_sort=float(q.ms_sort), ms_chain=float(q.ms_chain),
+                       ms_align=float(r.ms_total), ms_subgraph=float(r.ms_subgraph), ms_dp=float(r.ms_dp),
+                       ms_traceback=float(r.ms_traceback), kernels=kt_map + kt_aln)
+            L.vga_align_result_free(a)
+        finally:
+            L.vga_map_result_free(m)
+        return out
 
     def close(self):
         if self.h:

@@ -344,7 +344,9 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
         }
     }
     res->poa_problems = n;
-    for (uint64_t p = 0; p < n; p++) { res->poa_rows += pr->n_rows[p]; res->poa_cells += pr->n_cells[p]; }
+    for (uint64_t p = 0; p < n; p++) {
+        res->poa_rows += pr->n_rows[p]; res->poa_cells += pr->n_cells[p]; res->poa_value_cells += pr->n_value_cells[p];
+    }
     res->ms_subgraph = (float)std::chrono::duration<double, std::milli>(t1 - t0).count();
     res->ms_dp = pr ? pr->ms_dp : 0.f;
     res->ms_traceback = pr ? pr->ms_traceback : 0.f;

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(NT) void k_poa_dp(
     const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds, poa_dev_params P,
     int32_t *row_beg, int32_t *row_end, uint64_t *row_doff, uint64_t *row_voff, int32_t *row_lmax, int32_t *row_rmax,
     uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size, int32_t *__restrict__ out_score,
-    uint32_t *__restrict__ out_row, int32_t *__restrict__ out_status, uint64_t *__restrict__ out_cells)
+    uint32_t *__restrict__ out_row, int32_t *__restrict__ out_status, uint64_t *__restrict__ out_cells,
+    uint64_t *__restrict__ out_vcells)
 {
     constexpr int NW = NT / 64;
     __shared__ int32_t sA1[2][NT + 1];
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp(
 
     int prev_beg = 0, prev_end = 0, prev_lmax = 0, prev_rmax = 0;
     uint64_t prev_voff = 0;
-    uint64_t cells = 0;
+    uint64_t cells = 0, vcells = 0;
 
     for (uint32_t r = 0; r <= pb.N && !failed; r++) {
         const uint32_t flags = rflags[r];
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp(
         }
         const int W = end - beg + 1;
         if (r > 0) cells += (uint64_t)W;
+        if (last) vcells += (uint64_t)W;
         const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u));
         if (failed) break;
         uint64_t voff;
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp(
 
     if (tid == 0) {
         out_cells[blockIdx.x] = cells;
+        out_vcells[blockIdx.x] = vcells;
         if (failed) {
             out_status[blockIdx.x] = POA_ST_POOL;
             out_score[blockIdx.x] = POA_NEG;
@@ -502,7 +505,7 @@ extern "C" void vga_poa_result_free(vga_poa_result *r)
     if (!r) return;
     free(r->ok); free(r->best_score); free(r->path_off); free(r->abpoa_nodes); free(r->graph_nodes);
     free(r->aln_start_offset); free(r->aln_end_offset); free(r->n_aligned_bases); free(r->cigar_off);
-    free(r->cigar); free(r->cs_off); free(r->cs); free(r->n_rows); free(r->n_cells);
+    free(r->cigar); free(r->cs_off); free(r->cs); free(r->n_rows); free(r->n_cells); free(r->n_value_cells);
     free(r);
 }
 
@@ -533,6 +536,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     res->cs_off = pmalloc<uint64_t>(n + 1);
     res->n_rows = pmalloc<uint64_t>(n);
     res->n_cells = pmalloc<uint64_t>(n);
+    res->n_value_cells = pmalloc<uint64_t>(n);
     res->path_off[0] = res->cigar_off[0] = res->cs_off[0] = 0;
     vga_timers_reset(ctx);
     if (n == 0) {
@@ -624,7 +628,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     vga_dbuf<uint8_t> d_base, d_flags, d_npred, d_ops;
     vga_dbuf<int32_t> d_remain, d_beg, d_end, d_lmax, d_rmax, d_score, d_status;
     vga_dbuf<uint32_t> d_pstart, d_preds, d_sink, d_row, d_orow, d_nops;
-    vga_dbuf<uint64_t> d_doff, d_voff, d_cells;
+    vga_dbuf<uint64_t> d_doff, d_voff, d_cells, d_vcells;
     vga_dbuf<char> d_q;
     vga_dbuf<unsigned long long> d_next;
     POA_CHECK(d_probs.reserve(n)); POA_CHECK(d_base.reserve(tot_rows)); POA_CHECK(d_flags.reserve(tot_rows));
@@ -632,7 +636,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     POA_CHECK(d_preds.reserve(h_preds.size())); POA_CHECK(d_sink.reserve(h_sink.size())); POA_CHECK(d_q.reserve(h_q.size()));
     POA_CHECK(d_beg.reserve(tot_rows)); POA_CHECK(d_end.reserve(tot_rows)); POA_CHECK(d_doff.reserve(tot_rows));
     POA_CHECK(d_voff.reserve(tot_rows)); POA_CHECK(d_lmax.reserve(tot_rows)); POA_CHECK(d_rmax.reserve(tot_rows));
-    POA_CHECK(d_score.reserve(n)); POA_CHECK(d_status.reserve(n)); POA_CHECK(d_row.reserve(n)); POA_CHECK(d_cells.reserve(n));
+    POA_CHECK(d_score.reserve(n)); POA_CHECK(d_status.reserve(n)); POA_CHECK(d_row.reserve(n)); POA_CHECK(d_cells.reserve(n)); POA_CHECK(d_vcells.reserve(n));
     POA_CHECK(d_ops.reserve(tot_ops)); POA_CHECK(d_orow.reserve(tot_ops)); POA_CHECK(d_nops.reserve(n));
     POA_CHECK(d_next.reserve(1));
     POA_CHECK(hipMemcpyAsync(d_probs.p, probs.data(), n * sizeof(poa_prob), hipMemcpyHostToDevice, st));
@@ -676,7 +680,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     };
     std::vector<int32_t> h_status(n), h_score(n);
     std::vector<uint32_t> h_row(n), h_nops(n);
-    std::vector<uint64_t> h_cells(n);
+    std::vector<uint64_t> h_cells(n), h_vcells(n);
     std::vector<uint8_t> h_ops(tot_ops);
     std::vector<uint32_t> h_orow(tot_ops);
 
@@ -699,7 +703,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
         hipLaunchKernelGGL(k_poa_dp<256>, dim3(nb), dim3(256), 0, st, d_probs.p + p0, d_q.p, d_base.p, d_flags.p, d_npred.p,
                            d_remain.p, d_pstart.p, d_preds.p, d_sink.p, P, d_beg.p, d_end.p, d_doff.p, d_voff.p, d_lmax.p,
                            d_rmax.p, d_pool, d_next.p, pool_size, d_score.p + p0, d_row.p + p0, d_status.p + p0,
-                           d_cells.p + p0);
+                           d_cells.p + p0, d_vcells.p + p0);
         vga_timer_end(ctx, t_dp);
         int t_tb = vga_timer_begin(ctx, "poa_traceback", 0);
         hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, d_probs.p + p0, d_flags.p, d_npred.p,
@@ -729,6 +733,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     POA_CHECK(hipMemcpyAsync(h_row.data(), d_row.p, n * 4, hipMemcpyDeviceToHost, st));
     POA_CHECK(hipMemcpyAsync(h_nops.data(), d_nops.p, n * 4, hipMemcpyDeviceToHost, st));
     POA_CHECK(hipMemcpyAsync(h_cells.data(), d_cells.p, n * 8, hipMemcpyDeviceToHost, st));
+    POA_CHECK(hipMemcpyAsync(h_vcells.data(), d_vcells.p, n * 8, hipMemcpyDeviceToHost, st));
     POA_CHECK(hipMemcpyAsync(h_ops.data(), d_ops.p, tot_ops, hipMemcpyDeviceToHost, st));
     POA_CHECK(hipMemcpyAsync(h_orow.data(), d_orow.p, tot_ops * 4, hipMemcpyDeviceToHost, st));
     POA_CHECK(hipStreamSynchronize(st));
@@ -750,6 +755,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
                     res->ok[p] = h_status[p] == POA_ST_OK ? 1 : 0;
                     res->best_score[p] = h_score[p];
                     res->n_cells[p] = h_cells[p];
+                    res->n_value_cells[p] = h_vcells[p];
                     res->aln_start_offset[p] = res->aln_end_offset[p] = res->n_aligned_bases[p] = 0;
                     if (!res->ok[p]) continue;
                     const poa_graph_host &g = G[p];
@@ -824,15 +830,15 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     res->ms_dp = vga_timer_sum(ctx, "poa_band_dp");
     res->ms_traceback = vga_timer_sum(ctx, "poa_traceback");
     res->ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
-    uint64_t all_cells = 0, all_rows = 0, all_q = 0;
-    for (uint64_t p = 0; p < n; p++) { all_cells += h_cells[p]; all_rows += G[p].N; all_q += G[p].qlen; }
-    for (auto &a : ctx->last_times) {
-        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells;
-        if (a.name == "poa_traceback") a.bytes = 0;
-    }
+    // byte model of the DP kernel: graph bases + query + 1 direction byte per cell
+    // + the 6-byte value rows of node-end bases, written once and read back at least once
+    uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
     for (uint64_t p = 0; p < n; p++) {
-        for (auto &a : ctx->last_times)
-            if (a.name == "poa_traceback") a.bytes += 5ull * h_nops[p];
+        all_cells += h_cells[p]; all_vcells += h_vcells[p]; all_rows += G[p].N; all_q += G[p].qlen; all_ops += h_nops[p];
+    }
+    for (auto &a : ctx->last_times) {
+        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + 12 * all_vcells;
+        if (a.name == "poa_traceback") a.bytes = 6 * all_ops;
     }
 #undef POA_CHECK
     *out = res;

@@ -1,0 +1,122 @@
+// vgaligner_main.cpp -- `vgaligner index` / `vgaligner map`: same flags, defaults and output naming as the
+// reference CLI (src/subcommands/cli.yml:1-175, index_main.rs:11-87, map_main.rs:12-118).
+#include "vgh.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+using namespace vgh;
+
+namespace {
+
+struct Flag { const char *shortf, *longf; bool takes_value; };
+
+const Flag INDEX_FLAGS[] = {{"-i", "--input", true}, {"-o", "--out-prefix", true}, {"-k", "--kmer-length", true},
+                            {"-e", "--max-furcations", true}, {"-m", "--max-degree", true}, {"-r", "--sampling-rate", true},
+                            {"-g", "--generate-mappings", false}, {"-p", "--mappings-path", true}, {"-t", "--n-threads", true}};
+const Flag MAP_FLAGS[] = {{"-i", "--index", true}, {"-f", "--input-file", true}, {"-o", "--out-prefix", true},
+                          {"-g", "--max-gap-length", true}, {"-r", "--max-mismatch-rate", true}, {"-c", "--chain-overlap-max", true},
+                          {"-a", "--chain-min-anchors", true}, {"-b", "--align-best-n", true}, {"-C", "--write-console", false},
+                          {"-D", "--also-align", false}, {"-t", "--n-threads", true}, {"-v", "--also-validate", false},
+                          {"-G", "--graph", true}, {"-P", "--validation-path", true}, {"-p", "--poa-aligner", true},
+                          {"-d", "--device", true}};
+
+template <size_t N>
+std::map<std::string, std::string> parse(const Flag (&flags)[N], int argc, char **argv, int first)
+{
+    std::map<std::string, std::string> m;
+    for (int i = first; i < argc; i++) {
+        const Flag *f = nullptr;
+        for (const Flag &c : flags)
+            if (!strcmp(argv[i], c.shortf) || !strcmp(argv[i], c.longf)) f = &c;
+        if (!f) throw Error(std::string("unknown argument ") + argv[i]);
+        if (f->takes_value) {
+            if (i + 1 >= argc) throw Error(std::string("missing value for ") + argv[i]);
+            m[f->longf + 2] = argv[++i];
+        } else m[f->longf + 2] = "1";
+    }
+    return m;
+}
+
+std::string need(const std::map<std::string, std::string> &m, const char *key)
+{
+    auto it = m.find(key);
+    if (it == m.end()) throw Error(std::string("the required argument --") + key + " was not provided");
+    return it->second;
+}
+std::string opt(const std::map<std::string, std::string> &m, const char *key, const std::string &dflt)
+{
+    auto it = m.find(key);
+    return it == m.end() ? dflt : it->second;
+}
+
+int index_main(int argc, char **argv)
+{
+    auto m = parse(INDEX_FLAGS, argc, argv, 2);
+    std::string in = need(m, "input");
+    std::string prefix = opt(m, "out-prefix", in.size() > 4 ? in.substr(0, in.size() - 4) : in);  // index_main.rs:16-18
+    uint64_t k = std::stoull(need(m, "kmer-length"));
+    uint64_t furc = std::stoull(opt(m, "max-furcations", "100")), deg = std::stoull(opt(m, "max-degree", "100"));
+    if (m.count("sampling-rate")) throw Error("--sampling-rate depends on ahash's hash values and is not supported");
+    if (m.count("generate-mappings")) fprintf(stderr, "[vgaligner] --generate-mappings (debug JSON) is not produced by this build\n");
+    Index ix = Index::build(HashGraph::from_gfa(in), k, furc, deg);
+    fprintf(stderr, "[vgaligner] Index with k=%llu built: %llu different kmers, %llu positions\n", (unsigned long long)k,
+            (unsigned long long)ix.n_kmers, (unsigned long long)ix.n_kmer_pos);
+    bool exact = prefix.size() >= 4 && prefix.compare(prefix.size() - 4, 4, ".idx") == 0;  // index.rs:267-278
+    ix.store(exact ? prefix : prefix + ".idx");
+    return 0;
+}
+
+int map_main(int argc, char **argv)
+{
+    auto m = parse(MAP_FLAGS, argc, argv, 2);
+    std::string idx = need(m, "index"), in = need(m, "input-file");
+    std::string dflt_prefix;  // map_main.rs:19-28 (strips 3 chars for ...fa / ...fasta, else 4)
+    auto ends = [&](const char *s) { size_t n = strlen(s); return in.size() >= n && in.compare(in.size() - n, n, s) == 0; };
+    dflt_prefix = (ends("fa") || ends("fasta")) ? in.substr(0, in.size() - 3) : in.substr(0, in.size() > 4 ? in.size() - 4 : 0);
+    MapOptions o;
+    std::string prefix = opt(m, "out-prefix", dflt_prefix);
+    o.max_gap = std::stoull(opt(m, "max-gap-length", "1000"));
+    o.max_mismatch_rate = std::stod(opt(m, "max-mismatch-rate", "0.1"));
+    o.chain_min_n_anchors = std::stoull(opt(m, "chain-min-anchors", "3"));
+    o.align_best_n = std::stoull(opt(m, "align-best-n", "1"));
+    o.write_console = m.count("write-console") > 0;
+    o.also_align = m.count("also-align") > 0;
+    o.poa_aligner = need(m, "poa-aligner");  // cli.yml:169-175: required
+    o.device = std::stoi(opt(m, "device", "0"));
+    if (m.count("also-validate")) fprintf(stderr, "[vgaligner] --also-validate is not supported by this build (debug aid)\n");
+    if (o.also_align && !m.count("graph")) throw Error("--also-align needs --graph (the reference unwraps it, map.rs:157)");
+    bool exact = idx.size() >= 4 && idx.compare(idx.size() - 4, 4, ".idx") == 0;
+    Index ix = Index::load(exact ? idx : idx + ".idx");
+    std::vector<QuerySequence> reads = read_seqs_from_file(in);
+    fprintf(stderr, "[vgaligner] Found %zu reads!\n", reads.size());
+    vga_ctx *ctx = nullptr;
+    if (vga_ctx_create(o.device, &ctx) != VGA_OK) throw Error("no MI355X device available (this build has no CPU path)");
+    vga_index_desc d;
+    Index::DescScratch sc;
+    ix.describe(d, sc);
+    if (vga_index_upload(ctx, &d) != VGA_OK) { std::string e = vga_last_error(ctx); vga_ctx_destroy(ctx); throw Error(e); }
+    MapOutput out = map_reads(ctx, ix, reads, o, prefix);
+    fprintf(stderr, "[vgaligner] Chaining took: %.0f ms\n", out.ms_map);
+    if (o.also_align) fprintf(stderr, "[vgaligner] Alignment took: %.0f ms; Found %llu alignments!\n", out.ms_align, (unsigned long long)out.n_reads);
+    if (o.write_console) fputs(o.also_align ? out.alignments_gaf.c_str() : out.chains_gaf.c_str(), stdout);
+    vga_ctx_destroy(ctx);
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    try {
+        if (argc >= 2 && !strcmp(argv[1], "index")) return index_main(argc, argv);
+        if (argc >= 2 && !strcmp(argv[1], "map")) return map_main(argc, argv);
+        fprintf(stderr, "vgaligner 0.7 (MI355X build)\nUSAGE:\n  vgaligner index -i <graph.gfa> -k <K> [-o prefix] [-e 100] [-m 100]\n"
+                        "  vgaligner map -i <index> -f <reads.fa|fq> -p abpoa [-o prefix] [-g 1000] [-a 3] [-b 1] [-D -G <graph.gfa>] [-C]\n");
+        return 2;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "vgaligner: %s\n", e.what());
+        return 101;  // a Rust panic exits with 101
+    }
+}

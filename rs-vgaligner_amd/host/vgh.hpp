@@ -1,0 +1,126 @@
+// vgh.hpp -- C++ host side of the MI355X vgaligner: everything around the C ABI of libvga_hip.so.
+//
+// Mirrors the reference's public interface for the map -> chain -> align path (same names, argument
+// meaning and error behaviour; panics become vgh::Error):
+//   HashGraph / from_gfa ........ handlegraph 0.5.0 + gfa 0.8.0 as used at src/subcommands/index_main.rs:72-74
+//   Index::build ................ src/index.rs:109-281 (+ src/utils.rs:81-146, src/kmer.rs:277-505, 816-928,
+//                                 src/dna.rs:5-33)
+//   read_seqs_from_file ......... src/io.rs:74-162
+//   map_reads ................... src/map.rs:27-216   (anchors/chains/alignments come from the GPU)
+//   GAFAlignment ................ src/align.rs:746-1028, 1096-1168
+//   CLI ......................... src/subcommands/cli.yml, index_main.rs, map_main.rs
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vga_hip.h"
+
+namespace vgh {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+typedef uint64_t Handle;  // (id << 1) | is_reverse
+inline Handle pack(uint64_t id, bool rev) { return (id << 1) | (rev ? 1u : 0u); }
+inline uint64_t id_of(Handle h) { return h >> 1; }
+inline bool is_rev(Handle h) { return (h & 1) != 0; }
+inline Handle flip(Handle h) { return h ^ 1; }
+
+// ---- graph ------------------------------------------------------------------------------------
+struct Node {
+    std::string seq;
+    std::vector<Handle> left, right;  // insertion order, relative to the forward orientation
+    bool present = false;
+};
+
+struct Path {
+    std::string name;
+    std::vector<Handle> steps;
+};
+
+class HashGraph {
+  public:
+    std::vector<Node> nodes;  // indexed by id
+    uint64_t min_id = UINT64_MAX, max_id = 0, n_nodes = 0;
+    std::vector<Path> paths;
+
+    Handle create_handle(const std::string &seq, uint64_t id);
+    void create_edge(Handle left, Handle right);
+    std::string sequence(Handle h) const;
+    size_t node_len(uint64_t id) const { return nodes[id].seq.size(); }
+    // handle_edges_iter(h, Direction::Left | Right)
+    std::vector<Handle> neighbors(Handle h, bool left) const;
+    // GFAParser::parse_file + HashGraph::from_gfa
+    static HashGraph from_gfa(const std::string &path);
+};
+
+// ---- index ------------------------------------------------------------------------------------
+struct NodeRef {
+    uint64_t seq_idx, edge_idx, edges_to_node;
+};
+
+struct Index {
+    uint64_t kmer_length = 0, seq_length = 0, n_edges = 0, n_nodes = 0, n_kmers = 0, n_kmer_pos = 0;
+    std::string seq_fwd, seq_rev;
+    std::vector<uint8_t> seq_bv;
+    std::vector<Handle> edges;
+    std::vector<NodeRef> node_ref;
+    std::string kmer_keys;              // n_kmers * k, sorted
+    std::vector<uint64_t> kmer_starts;  // the MPHF's values
+    std::vector<vga_kmerpos> kmer_pos_table;
+
+    static Index build(const HashGraph &g, uint64_t kmer_length, uint64_t max_furcations, uint64_t max_degree);
+    // own container format ("VGAIDX1"); the reference's bincode .idx needs boomphf/bv/ahash internals
+    void store(const std::string &path) const;
+    static Index load(const std::string &path);
+    // fills a vga_index_desc whose pointers stay valid while *this and `scratch` live
+    struct DescScratch {
+        std::vector<uint64_t> seq_idx, edge_idx, edges_to;
+    };
+    void describe(vga_index_desc &d, DescScratch &scratch) const;
+
+    uint64_t get_bv_select(uint64_t element_no) const;
+    uint64_t node_id_from_fwd_pos(uint64_t pos) const;
+};
+
+// ---- reads ------------------------------------------------------------------------------------
+struct QuerySequence {
+    std::string name, seq;
+};
+std::vector<QuerySequence> read_seqs_from_file(const std::string &filename);
+
+// ---- GAF --------------------------------------------------------------------------------------
+std::string gaf_placeholder(const QuerySequence &q);
+std::string gaf_from_chain(const Index &ix, const QuerySequence &q, const vga_map_result *m, uint64_t read, uint64_t chain);
+std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a, uint64_t read);
+
+// ---- map_reads --------------------------------------------------------------------------------
+struct MapOptions {
+    uint64_t bandwidth = 50;             // map_main.rs:103
+    uint64_t max_gap = 1000;             // -g
+    uint64_t chain_min_n_anchors = 3;    // -a
+    double secondary_chain_threshold = 0.5;
+    double max_mismatch_rate = 0.1;      // -r (parsed, unused by the reference's live code)
+    double max_mapq = 60.0;
+    bool write_console = false;          // -C
+    bool also_align = false;             // -D
+    uint64_t align_best_n = 1;           // -b
+    std::string poa_aligner = "abpoa";   // -p
+    int device = 0;
+};
+
+struct MapOutput {
+    std::string chains_gaf, alignments_gaf;
+    uint64_t n_reads = 0, n_aligned = 0, n_anchors = 0, poa_cells = 0;
+    double ms_map = 0, ms_align = 0;
+};
+
+// ctx must already hold the uploaded index.  out_prefix == "" writes no files.
+MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt,
+                    const std::string &out_prefix);
+
+}  // namespace vgh

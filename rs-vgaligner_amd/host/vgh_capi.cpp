@@ -1,0 +1,91 @@
+// vgh_capi.cpp -- C wrappers over the C++ host (for ctypes-driven tests and bench.py).
+#include "vgh.hpp"
+
+#include <cstring>
+
+using namespace vgh;
+
+namespace {
+thread_local std::string g_err;
+char *dup_str(const std::string &s)
+{
+    char *p = (char *)malloc(s.size() + 1);
+    memcpy(p, s.c_str(), s.size() + 1);
+    return p;
+}
+struct IndexBox {
+    Index ix;
+    Index::DescScratch scratch;
+    vga_index_desc desc;
+};
+}  // namespace
+
+extern "C" {
+
+const char *vgh_last_error(void) { return g_err.c_str(); }
+
+// GFAParser::parse_file + HashGraph::from_gfa + Index::build (src/subcommands/index_main.rs:72-86)
+void *vgh_index_build_from_gfa(const char *gfa, uint64_t k, uint64_t max_furcations, uint64_t max_degree)
+{
+    try {
+        IndexBox *b = new IndexBox();
+        b->ix = Index::build(HashGraph::from_gfa(gfa), k, max_furcations, max_degree);
+        b->ix.describe(b->desc, b->scratch);
+        return b;
+    } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+
+void *vgh_index_load(const char *path)
+{
+    try {
+        IndexBox *b = new IndexBox();
+        b->ix = Index::load(path);
+        b->ix.describe(b->desc, b->scratch);
+        return b;
+    } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+
+int vgh_index_store(void *h, const char *path)
+{
+    try { ((IndexBox *)h)->ix.store(path); return 0; } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+void vgh_index_free(void *h) { delete (IndexBox *)h; }
+const vga_index_desc *vgh_index_desc(void *h) { return &((IndexBox *)h)->desc; }
+int vgh_index_upload(void *h, vga_ctx *ctx) { return vga_index_upload(ctx, &((IndexBox *)h)->desc); }
+
+// map_reads over in-memory reads; returns 0 and malloc'd GAF texts (free with vgh_free)
+int vgh_map_reads(vga_ctx *ctx, void *h, uint64_t n, const char *const *names, const char *const *seqs, uint64_t max_gap,
+                  uint64_t chain_min_n_anchors, int also_align, uint64_t align_best_n, const char *out_prefix,
+                  char **chains_gaf, char **alignments_gaf, uint64_t *n_aligned)
+{
+    try {
+        std::vector<QuerySequence> in(n);
+        for (uint64_t i = 0; i < n; i++) in[i] = {names[i], seqs[i]};
+        MapOptions opt;
+        opt.max_gap = max_gap;
+        opt.chain_min_n_anchors = chain_min_n_anchors;
+        opt.also_align = also_align != 0;
+        opt.align_best_n = align_best_n;
+        MapOutput o = map_reads(ctx, ((IndexBox *)h)->ix, in, opt, out_prefix ? out_prefix : "");
+        if (chains_gaf) *chains_gaf = dup_str(o.chains_gaf);
+        if (alignments_gaf) *alignments_gaf = dup_str(o.alignments_gaf);
+        if (n_aligned) *n_aligned = o.n_aligned;
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+// read_seqs_from_file: returns the number of reads or -1; names/seqs are malloc'd arrays of malloc'd strings
+int64_t vgh_read_seqs_from_file(const char *path, char ***names, char ***seqs)
+{
+    try {
+        std::vector<QuerySequence> v = read_seqs_from_file(path);
+        *names = (char **)malloc((v.size() + 1) * sizeof(char *));
+        *seqs = (char **)malloc((v.size() + 1) * sizeof(char *));
+        for (size_t i = 0; i < v.size(); i++) { (*names)[i] = dup_str(v[i].name); (*seqs)[i] = dup_str(v[i].seq); }
+        return (int64_t)v.size();
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+void vgh_free(void *p) { free(p); }
+}

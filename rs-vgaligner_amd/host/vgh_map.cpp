@@ -1,0 +1,150 @@
+// vgh_map.cpp -- reads, GAF records and the map_reads driver.
+//   read_seqs_from_file ........ src/io.rs:74-162
+//   GAFAlignment::from_chain ... src/align.rs:762-911 (+ AnchorPosOnGraph::new, src/chain.rs:90-127)
+//   from_placeholder_chain ..... src/align.rs:913-930
+//   generate_alignment ......... src/align.rs:1096-1168
+//   GAFAlignment::to_string .... src/align.rs:971-1027
+//   map_reads .................. src/map.rs:27-216, write_gaf_to_file 219-226
+// The reference's debug printing inside the hot loops is not part of the contract and is not reproduced.
+#include "vgh.hpp"
+
+#include <cstring>
+#include <fstream>
+
+namespace vgh {
+
+std::vector<QuerySequence> read_seqs_from_file(const std::string &filename)
+{
+    std::ifstream in(filename);
+    if (!in) throw Error("cannot open " + filename);
+    size_t dot = filename.find_last_of('.');
+    std::string ext = dot == std::string::npos ? "" : filename.substr(dot + 1);
+    bool fasta = ext == "fasta" || ext == "fa", fastq = ext == "fastq" || ext == "fq";
+    if (!fasta && !fastq) throw Error("Unrecognized file type");  // io.rs:86
+    std::vector<QuerySequence> seqs;
+    std::string line;
+    auto chomp = [](std::string &s) { if (!s.empty() && s.back() == '\r') s.pop_back(); };
+    if (fasta) {
+        // io.rs:100-122: every non-empty sequence line is its own read; the 2nd+ line under one header gets
+        // the name suffixed with 1, 2, ...
+        std::string name;
+        int same = 0;
+        while (std::getline(in, line)) {
+            chomp(line);
+            if (!line.empty() && line[0] == '>') { name = line.substr(1); same = 0; }
+            else if (!line.empty()) {
+                seqs.push_back({same == 0 ? name : name + std::to_string(same), line});
+                same++;
+            }
+        }
+    } else {
+        std::string l1, l2, l3, l4;  // io.rs:124-130: strict 4-line records
+        while (std::getline(in, l1) && std::getline(in, l2) && std::getline(in, l3) && std::getline(in, l4)) {
+            chomp(l1); chomp(l2);
+            seqs.push_back({l1.empty() ? "" : l1.substr(1), l2});
+        }
+    }
+    return seqs;
+}
+
+std::string gaf_placeholder(const QuerySequence &q)
+{
+    return q.name + "\t" + std::to_string(q.seq.size()) + "\t*\t*\t*\t*\t*\t*\t*\t*\t*\t0\t*\n";
+}
+
+std::string gaf_from_chain(const Index &ix, const QuerySequence &q, const vga_map_result *m, uint64_t read, uint64_t chain)
+{
+    if (m->chain_placeholder[chain]) return gaf_placeholder(q);
+    const uint64_t a0 = m->anchor_off[read];
+    const uint64_t c0 = m->chain_anchor_off[chain], c1 = m->chain_anchor_off[chain + 1];
+    const uint64_t k = ix.kmer_length;
+    std::string path;
+    for (uint64_t t = c0; t < c1; t++) {
+        const uint64_t ai = a0 + m->chain_anchor_idx[t];
+        const uint64_t tb = m->target_begin[ai], te_incl = (uint64_t)m->target_end[ai] - 1;
+        const uint64_t fn = ix.node_id_from_fwd_pos(tb), ln = ix.node_id_from_fwd_pos(te_incl);
+        path += "(>" + std::to_string(fn) + ":" + std::to_string(tb - ix.get_bv_select(fn)) + ",>" + std::to_string(ln) + ":" +
+                std::to_string(te_incl - ix.get_bv_select(ln)) + "),";
+    }
+    const uint64_t first = a0 + m->chain_anchor_idx[c0], last = a0 + m->chain_anchor_idx[c1 - 1];
+    // plen pstart pend residue block = 0; mapq = min(f64::MIN as u64, 254) = 0 (align.rs:904, chain.rs:203)
+    return q.name + "\t" + std::to_string(q.seq.size()) + "\t" + std::to_string(m->query_begin[first]) + "\t" +
+           std::to_string(m->query_begin[last] + k) + "\t+\t" + path + "\t0\t0\t0\t0\t0\t0\tta:Z:chain,n_anchors: " +
+           std::to_string(c1 - c0) + "\n";
+}
+
+std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a, uint64_t r)
+{
+    if (!a->aligned[r]) return gaf_placeholder(q);
+    std::string path;
+    for (uint64_t t = a->path_off[r]; t < a->path_off[r + 1]; t++) {
+        Handle h = a->path_handles[t];
+        path += (is_rev(h) ? "<" : ">") + std::to_string(id_of(h));
+    }
+    const std::string len = std::to_string(q.seq.size());
+    // align.rs:1145-1167: qstart 0, qend len, '+', residue 0, mapq 255, literal "as:i:-30"
+    return q.name + "\t" + len + "\t0\t" + len + "\t+\t" + path + "\t" + std::to_string(a->path_length[r]) + "\t" +
+           std::to_string(a->path_start[r]) + "\t" + std::to_string(a->path_end[r]) + "\t0\t" + std::to_string(a->block_length[r]) +
+           "\t255\tas:i:-30 " + (a->cs + a->cs_off[r]) + ",cg:Z:" + (a->cigar + a->cigar_off[r]) + "\n";
+}
+
+static void write_file(const std::string &name, const std::string &body)
+{
+    std::ofstream o(name, std::ios::binary);
+    if (!o) throw Error("Couldn't create file " + name);
+    o.write(body.data(), body.size());
+    if (!o) throw Error("Couldn't write to file " + name);
+}
+
+MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt,
+                    const std::string &out_prefix)
+{
+    if (opt.poa_aligner != "abpoa") {
+        if (opt.poa_aligner == "rspoa") throw Error("the rspoa aligner is not available in the MI355X build yet; use -p abpoa");
+        throw Error("POA Aligner not recognized");  // map_main.rs:67
+    }
+    MapOutput out;
+    out.n_reads = inputs.size();
+    std::string concat;
+    std::vector<uint64_t> off(inputs.size() + 1, 0);
+    for (size_t i = 0; i < inputs.size(); i++) { concat += inputs[i].seq; off[i + 1] = concat.size(); }
+    vga_batch *b = nullptr;
+    if (vga_batch_create(ctx, concat.data(), off.data(), inputs.size(), &b) != VGA_OK) throw Error(vga_last_error(ctx));
+    vga_map_params mp;
+    vga_map_default_params(&mp);
+    mp.bandwidth = (uint32_t)opt.bandwidth;
+    mp.max_gap = opt.max_gap;
+    mp.chain_min_n_anchors = (uint32_t)opt.chain_min_n_anchors;
+    vga_map_result *m = nullptr;
+    if (vga_map_batch(b, &mp, &m) != VGA_OK) { vga_batch_destroy(b); throw Error(vga_last_error(ctx)); }
+    out.n_anchors = m->n_anchors;
+    out.ms_map = m->ms_total;
+    // chains GAF (map.rs:123-145): every chain of every read, in order
+    for (size_t r = 0; r < inputs.size(); r++)
+        for (uint64_t c = m->chain_off[r]; c < m->chain_off[r + 1]; c++) out.chains_gaf += gaf_from_chain(ix, inputs[r], m, r, c);
+    const bool same_file = out_prefix.size() >= 4 && out_prefix.compare(out_prefix.size() - 4, 4, ".gaf") == 0;
+    if (!out_prefix.empty()) write_file(same_file ? out_prefix : out_prefix + "-chains.gaf", out.chains_gaf);
+    if (opt.also_align) {
+        vga_poa_params pp;
+        vga_poa_default_params(&pp);
+        vga_align_result *a = nullptr;
+        if (vga_align_batch(b, m, (uint32_t)opt.align_best_n, &pp, &a) != VGA_OK) {
+            vga_map_result_free(m); vga_batch_destroy(b);
+            throw Error(vga_last_error(ctx));
+        }
+        out.ms_align = a->ms_total;
+        out.poa_cells = a->poa_cells;
+        for (size_t r = 0; r < inputs.size(); r++) {
+            out.alignments_gaf += gaf_from_alignment(inputs[r], a, r);
+            out.n_aligned += a->aligned[r];
+        }
+        // map.rs:174-178: a prefix ending in .gaf makes the alignments overwrite the chains file
+        if (!out_prefix.empty()) write_file(same_file ? out_prefix : out_prefix + "-alignments.gaf", out.alignments_gaf);
+        vga_align_result_free(a);
+    }
+    vga_map_result_free(m);
+    vga_batch_destroy(b);
+    return out;
+}
+
+}  // namespace vgh

@@ -1,0 +1,85 @@
+"""The C++ host (Index::build, FASTA/FASTQ reader, index file) checked against the oracle and the
+reference's fixtures.  Two independently written builders (C oracle, C++ product) must agree bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import DATA, oracle_index_arrays, pkg
+
+
+@pytest.mark.parametrize("gfa,k", [("test.gfa", 11), ("test.gfa", 3), ("DRB1-3123.gfa", 11), ("DRB1-3123.gfa", 7)])
+def test_host_index_equals_oracle_index(oracle, gfa, k):
+    path = os.path.join(DATA, gfa)
+    hi = pkg().HostIndex.build_from_gfa(path, k)
+    got = hi.arrays()
+    want = oracle_index_arrays(oracle.Index(oracle.Graph.from_gfa(path), k))
+    assert got["k"] == want["k"] and got["seq_fwd"] == want["seq_fwd"]
+    for key in ("node_seq_idx", "node_edge_idx", "node_edges_to", "edges", "kmer_starts"):
+        assert np.array_equal(got[key], np.asarray(want[key], dtype=np.uint64)), key
+    assert got["kmer_keys"] == want["kmer_keys"]
+    for f in ("start", "end", "start_orient", "end_orient"):
+        assert np.array_equal(got["kmer_pos_table"][f], want["kmer_pos_table"][f]), f
+
+
+def test_host_index_small_graph_vectors(tmp_path, oracle):
+    """src/index.rs:761-824 (linearisation, NodeRefs) and 1109-1129 (ACT -> F0..F3) through the C++ builder"""
+    gfa = tmp_path / "simple.gfa"
+    gfa.write_text("H\tVN:Z:1.0\nS\t1\tA\nS\t2\tCT\nS\t3\tGA\nS\t4\tGCA\nL\t1\t+\t2\t+\t0M\nL\t1\t+\t3\t+\t0M\n"
+                   "L\t2\t+\t4\t+\t0M\nL\t3\t+\t4\t+\t0M\n")
+    a = pkg().HostIndex.build_from_gfa(str(gfa), 3).arrays()
+    assert a["seq_fwd"] == b"ACTGAGCA"
+    assert a["node_seq_idx"].tolist() == [0, 1, 3, 5, 8]
+    assert a["node_edge_idx"].tolist() == [0, 2, 4, 6, 8]
+    assert a["node_edges_to"].tolist() == [0, 1, 1, 2, 0]
+    keys = [a["kmer_keys"][i:i + 3] for i in range(0, len(a["kmer_keys"]), 3)]
+    s = int(a["kmer_starts"][keys.index(b"ACT")])
+    t = a["kmer_pos_table"][s]
+    assert (int(t["start_orient"]), int(t["start"]), int(t["end_orient"]), int(t["end"])) == (0, 0, 0, 3)
+    assert int(a["kmer_pos_table"][s + 1]["start"]) == 2**64 - 1  # delimiter
+
+
+def test_host_index_store_load_roundtrip(tmp_path):
+    p = pkg()
+    hi = p.HostIndex.build_from_gfa(os.path.join(DATA, "test.gfa"), 11)
+    f = str(tmp_path / "t.idx")
+    hi.store(f)
+    a, b = hi.arrays(), p.HostIndex.load(f).arrays()
+    for key in a:
+        if key == "kmer_pos_table":
+            for fld in ("start", "end", "start_orient", "end_orient"):
+                assert np.array_equal(a[key][fld], b[key][fld])
+        elif isinstance(a[key], np.ndarray):
+            assert np.array_equal(a[key], b[key])
+        else:
+            assert a[key] == b[key]
+
+
+def test_host_errors_mirror_reference_panics(tmp_path):
+    p = pkg()
+    with pytest.raises(p.hostlib.HostError):  # kmer.rs:828 unwrap() on an empty k-mer list
+        p.HostIndex.build_from_gfa(os.path.join(DATA, "test.gfa"), 100)
+    bad = tmp_path / "ids.gfa"
+    bad.write_text("S\t2\tACGT\nS\t5\tAC\nL\t2\t+\t5\t+\t0M\n")
+    with pytest.raises(p.hostlib.HostError):  # ids must be 1..n
+        p.HostIndex.build_from_gfa(str(bad), 3)
+    with pytest.raises(p.hostlib.HostError):
+        p.HostIndex.load(str(bad))
+    with pytest.raises(p.hostlib.HostError):  # io.rs:86 "Unrecognized file type"
+        p.hostlib.read_seqs_from_file(str(bad))
+
+
+def test_host_reader_matches_reference_fixtures():
+    """src/io.rs:267-308"""
+    r = pkg().hostlib.read_seqs_from_file
+    assert r(os.path.join(DATA, "single-read-test.fa")) == [("seq0", "AAAAACGTTAAATTTGGCATCGTAGCAAAAA")]
+    assert r(os.path.join(DATA, "multiple-read-test.fa")) == [("seq0", "AAAAACGTTAAATTTGGCATCGTAGCAAAAA"),
+                                                                ("seq1", "TTTCGTTAAATTTGGCATCGTAGCTTT")]
+    assert len(r(os.path.join(DATA, "test.fq"))) == 1
+
+
+def test_host_reader_multiline_fasta(tmp_path):
+    """src/io.rs:100-122: every sequence line is a read; later lines get the name suffixed by a counter"""
+    f = tmp_path / "m.fa"
+    f.write_text(">a b\nACGT\nTTTT\n\nGG\n>c\nAA\n")
+    assert pkg().hostlib.read_seqs_from_file(str(f)) == [("a b", "ACGT"), ("a b1", "TTTT"), ("a b2", "GG"), ("c", "AA")]
