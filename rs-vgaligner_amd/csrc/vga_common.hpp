@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -59,6 +60,12 @@ struct vga_ctx {
     };
     std::vector<agg_t> last_times;
     int n_cu = 256;
+    // persistent, grow-only device workspaces (owned by the modules that use them): no hipMalloc/hipFree
+    // in the steady state of a call
+    void *map_ws = nullptr;
+    void (*map_ws_free)(void *) = nullptr;
+    void *poa_ws = nullptr;
+    void (*poa_ws_free)(void *) = nullptr;
 };
 
 struct vga_batch {
@@ -104,6 +111,21 @@ struct vga_dbuf {
         cap = 0;
     }
     ~vga_dbuf() { release(); }
+};
+
+// host-side phase tracing (VGA_TRACE=1): prints wall-clock deltas to stderr
+struct vga_trace {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    const char *fn;
+    explicit vga_trace(const char *f) : on(getenv("VGA_TRACE") != nullptr), t(std::chrono::steady_clock::now()), fn(f) {}
+    void mark(const char *what)
+    {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vga-trace] %s: %-28s %9.3f ms\n", fn, what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
 };
 
 // event timing helpers (vga_ctx.hip)

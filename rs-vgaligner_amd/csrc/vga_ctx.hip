@@ -51,6 +51,8 @@ extern "C" void vga_ctx_destroy(vga_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->map_ws && ctx->map_ws_free) ctx->map_ws_free(ctx->map_ws);
+    if (ctx->poa_ws && ctx->poa_ws_free) ctx->poa_ws_free(ctx->poa_ws);
     vga_index_release(ctx->index);
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

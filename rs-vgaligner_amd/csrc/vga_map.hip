@@ -334,7 +334,7 @@ struct map_ws {
     vga_dbuf<uint32_t> a_qb, a_tb, a_te, a_idx, key_b, val_b, s_qb, s_tb, s_te;
     vga_dbuf<double> f, curr_max, gap_cost;
     vga_dbuf<int32_t> pred_id, pred_pos;
-    vga_dbuf<uint32_t> chain_buf, chain_cnt, chain_words;
+    vga_dbuf<uint32_t> chain_buf, chain_cnt, chain_words, key_a;
 };
 
 template <typename T>
@@ -379,9 +379,14 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     const vga_dev_index &ix = ctx->index;
     const uint64_t R = b->n_reads;
     hipStream_t st = ctx->stream;
-    map_ws ws;
+    if (!ctx->map_ws) {
+        ctx->map_ws = new map_ws();
+        ctx->map_ws_free = [](void *p) { delete (map_ws *)p; };
+    }
+    map_ws &ws = *(map_ws *)ctx->map_ws;
     vga_timers_reset(ctx);
     auto t_host0 = std::chrono::steady_clock::now();
+    vga_trace tr("map");
 
     vga_map_result *res = (vga_map_result *)calloc(1, sizeof(vga_map_result));
     res->n_reads = R;
@@ -419,6 +424,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     std::vector<uint32_t> h_cnt(R);
     MAP_CHECK(hipMemcpyAsync(h_cnt.data(), ws.cnt.p, R * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MAP_CHECK(hipStreamSynchronize(st));
+    tr.mark("count kernel + sync");
     uint64_t total = 0;
     for (uint64_t r = 0; r < R; r++) {
         res->anchor_off[r] = total;
@@ -438,6 +444,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     MAP_CHECK(ws.chain_buf.reserve(3 * An + 2 * R + 2));
     MAP_CHECK(ws.chain_cnt.reserve(R)); MAP_CHECK(ws.chain_words.reserve(R));
 
+    tr.mark("workspace reserve");
     // gap cost table (src/chain.rs:348-354), host libm
     const uint64_t mg = params->max_gap;
     std::vector<double> gc(mg + 1);
@@ -463,7 +470,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     while ((1ull << nbits) <= ix.seq_length && nbits < 32) nbits++;
     const uint32_t n_pass = (nbits + 7) / 8;
     // the keys are sorted in place of a_te (ping) / key_b (pong); the original te is re-gathered from a copy
-    vga_dbuf<uint32_t> key_a;
+    vga_dbuf<uint32_t> &key_a = ws.key_a;
     MAP_CHECK(key_a.reserve(An));
     if (An) MAP_CHECK(hipMemcpyAsync(key_a.p, ws.a_te.p, An * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     int t3 = vga_timer_begin(ctx, "anchor_sort", (uint64_t)n_pass * 16 * total + 24 * total);
@@ -482,6 +489,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     vga_timer_end(ctx, t4);
     vga_timer_end(ctx, t_total);
 
+    tr.mark("launches");
     // ---- results to host
     res->anchor_id = xmalloc<uint32_t>(An);
     res->query_begin = xmalloc<uint32_t>(An);
@@ -504,6 +512,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     MAP_CHECK(hipMemcpyAsync(h_chain_cnt.data(), ws.chain_cnt.p, R * 4, hipMemcpyDeviceToHost, st));
     MAP_CHECK(hipMemcpyAsync(h_chain_words.data(), ws.chain_words.p, R * 4, hipMemcpyDeviceToHost, st));
     MAP_CHECK(hipStreamSynchronize(st));
+    tr.mark("kernels + D2H");
     vga_timers_collect(ctx);
 
     // ---- chains: discovery order per read, members reversed to ascending (src/chain.rs:546);
@@ -541,6 +550,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     }
     res->chain_off[R] = ci;
     res->chain_anchor_off[ci] = mi;
+    tr.mark("chain assembly");
     res->ms_probe = vga_timer_sum(ctx, "kmer_probe");
     res->ms_sort = vga_timer_sum(ctx, "anchor_sort");
     res->ms_chain = vga_timer_sum(ctx, "chain_dp");

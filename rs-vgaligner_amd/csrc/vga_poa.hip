@@ -65,9 +65,7 @@ __device__ __forceinline__ int poa_sub(const poa_dev_params &P, uint8_t g, uint8
 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_poa_dp(
-    const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint8_t *__restrict__ row_base,
-    const uint8_t *__restrict__ row_flags, const uint8_t *__restrict__ row_npred,
-    const int32_t *__restrict__ row_remain, const uint32_t *__restrict__ row_pred_start,
+    const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ row_meta,
     const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds, poa_dev_params P,
     int32_t *row_beg, int32_t *row_end, uint64_t *row_doff, uint64_t *row_voff, int32_t *row_lmax, int32_t *row_rmax,
     uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size, int32_t *__restrict__ out_score,
@@ -86,11 +84,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp(
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int qlen = (int)pb.qlen;
     const char *query = queries + pb.q0;
-    const uint8_t *rbase = row_base + pb.row0;
-    const uint8_t *rflags = row_flags + pb.row0;
-    const uint8_t *rnpred = row_npred + pb.row0;
-    const int32_t *rremain = row_remain + pb.row0;
-    const uint32_t *rpstart = row_pred_start + pb.row0;
+    const uint4 *rmeta = row_meta + pb.row0;  // {base | flags << 8 | npred << 16, remain, pred_start, -}: one scalar load per row
     const uint32_t *plist = preds + pb.pred0;
     volatile int32_t *vbeg = row_beg + pb.row0;
     volatile int32_t *vend = row_end + pb.row0;
@@ -132,11 +126,12 @@ __global__ __launch_bounds__(NT) void k_poa_dp(
     uint64_t cells = 0, vcells = 0;
 
     for (uint32_t r = 0; r <= pb.N && !failed; r++) {
-        const uint32_t flags = rflags[r];
+        const uint4 mt = rmeta[r];
+        const uint32_t flags = (mt.x >> 8) & 255u;
         const bool first = (flags & POA_FLAG_FIRST) != 0;
         const bool last = (flags & POA_FLAG_LAST) != 0;
-        const int np = r == 0 ? 0 : (first ? (int)rnpred[r] : 1);
-        const uint32_t ps = first ? rpstart[r] : 0;
+        const int np = r == 0 ? 0 : (first ? (int)((mt.x >> 16) & 255u) : 1);
+        const uint32_t ps = mt.z;
         // ---- band (abPOA adaptive band; pulls what the predecessors' maxima pushed)
         int mpl, mpr;
         if (r == 0) { mpl = 0; mpr = 0; }
@@ -153,7 +148,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp(
         int beg, end;
         if (!P.banded) { beg = 0; end = qlen; }
         else {
-            const int diag = qlen - rremain[r];
+            const int diag = qlen - (int)mt.y;
             const int lo = mpl < diag ? mpl : diag;
             const int hi = mpr > diag ? mpr : diag;
             beg = lo - bw; if (beg < 0) beg = 0;
@@ -177,7 +172,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp(
         uint8_t *d1row = pool + voff + 4ull * (uint64_t)W;
         uint8_t *d2row = d1row + W;
         uint8_t *drow = pool + doff;
-        const uint8_t gb = rbase[r];
+        const uint8_t gb = (uint8_t)(mt.x & 255u);
 
         int carry1 = POA_IDENT, carry2 = POA_IDENT, left1 = POA_IDENT, left2 = POA_IDENT;
         int best = INT32_MIN, lpos = beg, rpos = beg;
@@ -332,10 +327,333 @@ __global__ __launch_bounds__(NT) void k_poa_dp(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// K4 (LDS form).  Same recurrences and outputs as k_poa_dp, but the row that was just filled stays in LDS,
+// indexed by ABSOLUTE query column and overwritten in place by the next row:
+//   Hs[j]  int32  H of the current "previous row" at column j
+//   Ds[j]  uint16 d1 | d2 << 8
+// so the common predecessor (the row directly above) costs two LDS reads instead of an L2 round trip, the
+// workgroup barriers only wait for LDS (s_waitcnt lgkmcnt(0); s_barrier -- direction bytes and node-end value
+// rows are fire-and-forget global stores), and a row needs ceil(W/NT) + 1 barriers.
+// In-place hazard: inside a chunk every lane reads Hs[j-1], Hs[j] before the chunk's barrier and writes Hs[j]
+// after it; the first lane of the NEXT chunk needs the old Hs of this chunk's last column, which the last lane
+// parks in `edge` before the barrier.
+// Rows whose predecessor is not the row directly above (bubble arms, multi-predecessor rows) read that
+// predecessor's 6-byte value row from HBM; such a row starts with a full __syncthreads() (vmcnt(0)) so that the
+// stores it depends on have landed.
+// The query itself is staged in LDS too and the per-row metadata is one 16-byte scalar load, so the row loop
+// issues no vector loads at all: gfx950 retires vector memory operations in order, and a load behind the
+// direction-byte stores would wait for them to reach HBM.
+// Requires 7 * (max_qlen + 1) + scratch bytes of dynamic LDS (2 workgroups per CU up to ~11 kbp reads).
+#define POA_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_poa_dp_lds(
+    const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ row_meta,
+    const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds, poa_dev_params P,
+    int32_t *row_beg, int32_t *row_end, uint64_t *row_doff, uint64_t *row_voff, int32_t *row_lmax, int32_t *row_rmax,
+    uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size, int32_t *__restrict__ out_score,
+    uint32_t *__restrict__ out_row, int32_t *__restrict__ out_status, uint64_t *__restrict__ out_cells,
+    uint64_t *__restrict__ out_vcells, uint32_t lds_cols)
+{
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int32_t *Hs = (int32_t *)smem;
+    uint16_t *Ds = (uint16_t *)(smem + 4ull * lds_cols);
+    uint8_t *Qs = smem + 6ull * lds_cols;  // the query, staged once: no vector loads in the row loop
+    int32_t *scr = (int32_t *)(smem + ((7ull * lds_cols + 15ull) & ~15ull));
+    int32_t *sW1 = scr;               // [2][NW] inclusive wave maxima of a1
+    int32_t *sW2 = sW1 + 2 * NW;      // [2][NW]
+    int32_t *sL1 = sW2 + 2 * NW;      // [2][NW] a1 of each wave's last lane
+    int32_t *sL2 = sL1 + 2 * NW;      // [2][NW]
+    int32_t *sRed = sL2 + 2 * NW;     // [NW][3]
+    int32_t *edgeH = sRed + 3 * NW;   // [2]
+    int32_t *edgeD = edgeH + 2;       // [2]
+    unsigned long long *s_alloc = (unsigned long long *)(edgeD + 2);
+
+    const poa_prob pb = probs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int qlen = (int)pb.qlen;
+    const char *query = queries + pb.q0;
+    const uint4 *rmeta = row_meta + pb.row0;  // {base | flags << 8 | npred << 16, remain, pred_start, -}: one scalar load per row
+    const uint32_t *plist = preds + pb.pred0;
+    volatile int32_t *vbeg = row_beg + pb.row0;
+    volatile int32_t *vend = row_end + pb.row0;
+    volatile uint64_t *vvoff = row_voff + pb.row0;
+    volatile int32_t *vlmax = row_lmax + pb.row0;
+    volatile int32_t *vrmax = row_rmax + pb.row0;
+    uint64_t *gdoff = row_doff + pb.row0;
+
+    const int o1 = P.o1, e1 = P.e1, o2 = P.o2, e2 = P.e2;
+    const int bw = (int)pb.w;
+
+    uint64_t dcur = 0, dend = 0, vcur = 0, vendp = 0;
+    bool failed = false;
+    auto take_chunk = [&](uint64_t &cur, uint64_t &end) {
+        __syncthreads();
+        if (tid == 0) *s_alloc = atomicAdd(pool_next, (unsigned long long)POA_CHUNK);
+        __syncthreads();
+        uint64_t b = *s_alloc;
+        if (b + POA_CHUNK > pool_size) failed = true;
+        cur = b;
+        end = b + POA_CHUNK;
+    };
+    auto alloc = [&](uint64_t &cur, uint64_t &end, uint64_t bytes) -> uint64_t {
+        bytes = (bytes + 15ull) & ~15ull;
+        if (cur + bytes > end) take_chunk(cur, end);
+        uint64_t r = cur;
+        cur += bytes;
+        return r;
+    };
+
+    for (int t = tid; t < qlen; t += NT) Qs[t] = (uint8_t)query[t];
+    __syncthreads();
+
+    int prev_beg = 0, prev_end = -1, prev_lmax = 0, prev_rmax = 0;
+    uint64_t cells = 0, vcells = 0;
+
+    for (uint32_t r = 0; r <= pb.N && !failed; r++) {
+        const uint4 mt = rmeta[r];
+        const uint32_t flags = (mt.x >> 8) & 255u;
+        const bool first = (flags & POA_FLAG_FIRST) != 0;
+        const bool last = (flags & POA_FLAG_LAST) != 0;
+        const int np = r == 0 ? 0 : (first ? (int)((mt.x >> 16) & 255u) : 1);
+        const uint32_t ps = mt.z;
+        // does any predecessor live in HBM (i.e. is not the row directly above)?
+        bool far = false;
+        if (first)
+            for (int t = 0; t < np; t++) far |= plist[ps + t] != r - 1;
+        if (far) __syncthreads();  // vmcnt(0) + barrier: value rows / row arrays of far predecessors have landed
+        int mpl, mpr;
+        if (r == 0) { mpl = 0; mpr = 0; }
+        else if (!first) { mpl = prev_lmax + 1; mpr = prev_rmax + 1; }
+        else {
+            mpl = INT32_MAX; mpr = 0;
+            for (int t = 0; t < np; t++) {
+                const uint32_t p = plist[ps + t];
+                int lm, rm;
+                if (p == r - 1) { lm = prev_lmax + 1; rm = prev_rmax + 1; }
+                else { lm = vlmax[p] + 1; rm = vrmax[p] + 1; }
+                mpl = lm < mpl ? lm : mpl;
+                mpr = rm > mpr ? rm : mpr;
+            }
+        }
+        int beg, end;
+        if (!P.banded) { beg = 0; end = qlen; }
+        else {
+            const int diag = qlen - (int)mt.y;
+            const int lo = mpl < diag ? mpl : diag;
+            const int hi = mpr > diag ? mpr : diag;
+            beg = lo - bw; if (beg < 0) beg = 0;
+            end = hi + bw; if (end > qlen) end = qlen;
+        }
+        const int W = end - beg + 1;
+        if (r > 0) cells += (uint64_t)W;
+        if (last) vcells += (uint64_t)W;
+        const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u));
+        if (failed) break;
+        uint64_t voff = 0;
+        if (last) { voff = alloc(vcur, vendp, 6ull * (uint64_t)W); if (failed) break; }
+        if (tid == 0) {
+            vbeg[r] = beg;
+            vend[r] = end;
+            gdoff[r] = doff;
+            vvoff[r] = voff;
+        }
+        int32_t *Hrow = (int32_t *)(pool + voff);
+        uint8_t *d1row = pool + voff + 4ull * (uint64_t)W;
+        uint8_t *d2row = d1row + W;
+        uint8_t *drow = pool + doff;
+        const uint8_t gb = (uint8_t)(mt.x & 255u);
+
+        int carry1 = POA_IDENT, carry2 = POA_IDENT, left1 = POA_IDENT, left2 = POA_IDENT;
+        int best = INT32_MIN, lpos = beg, rpos = beg;
+        int buf = 0;
+        for (int c0 = 0; c0 < W; c0 += NT, buf ^= 1) {
+            const int c = c0 + tid;
+            const int j = beg + c;
+            const bool act = j <= end;
+            int m = POA_NEG, ev1 = POA_NEG, ev2 = POA_NEG;
+            int pm = 0, p1 = 0, p2 = 0;
+            int of1 = 0, of2 = 0;
+            int ht, hts = 0;
+            if (r > 0) {
+                const uint8_t qc = (act && j >= 1) ? Qs[j - 1] : (uint8_t)0;
+                const int s = poa_sub(P, gb, qc);
+                for (int t = 0; t < np; t++) {
+                    const uint32_t p = first ? plist[ps + t] : r - 1;
+                    if (p == r - 1) {
+                        // the row directly above: LDS, absolute columns
+                        int hj = POA_NEG, dj = 0;
+                        const bool inj = act && j >= prev_beg && j <= prev_end;
+                        if (inj) { hj = Hs[j]; dj = Ds[j]; }
+                        if (tid == NT - 1) { edgeH[buf] = hj; edgeD[buf] = inj ? 1 : 0; }
+                        int hm = POA_NEG;
+                        bool inm = act && j >= 1 && j - 1 >= prev_beg && j - 1 <= prev_end;
+                        if (inm) {
+                            if (tid == 0 && c0 > 0) { hm = edgeH[buf ^ 1]; inm = edgeD[buf ^ 1] != 0; }
+                            else hm = Hs[j - 1];
+                        }
+                        if (inm) {
+                            const int cnd = hm + s;
+                            if (cnd > m) { m = cnd; pm = t; }
+                        }
+                        if (inj) {
+                            const int dd1 = dj & 255, dd2 = dj >> 8;
+                            const int c1 = hj - e1 - dd1;
+                            if (c1 > ev1) { ev1 = c1; p1 = t; of1 = dd1 == o1; }
+                            const int c2 = hj - e2 - dd2;
+                            if (c2 > ev2) { ev2 = c2; p2 = t; of2 = dd2 == o2; }
+                        }
+                    } else {
+                        const int bp = vbeg[p], ep = vend[p];
+                        const uint64_t pv = vvoff[p];
+                        const int Wp = ep - bp + 1;
+                        const int32_t *Hp = (const int32_t *)(pool + pv);
+                        const uint8_t *d1p = pool + pv + 4ull * (uint64_t)Wp;
+                        const uint8_t *d2p = d1p + Wp;
+                        if (act) {
+                            const int jm = j - 1 - bp;
+                            if (j >= 1 && jm >= 0 && j - 1 <= ep) {
+                                const int cnd = Hp[jm] + s;
+                                if (cnd > m) { m = cnd; pm = t; }
+                            }
+                            const int jj = j - bp;
+                            if (jj >= 0 && j <= ep) {
+                                const int hj = Hp[jj];
+                                const int dd1 = d1p[jj], dd2 = d2p[jj];
+                                const int c1 = hj - e1 - dd1;
+                                if (c1 > ev1) { ev1 = c1; p1 = t; of1 = dd1 == o1; }
+                                const int c2 = hj - e2 - dd2;
+                                if (c2 > ev2) { ev2 = c2; p2 = t; of2 = dd2 == o2; }
+                            }
+                        }
+                    }
+                }
+                ht = m;
+                if (ev1 > ht) { ht = ev1; hts = 1; }
+                if (ev2 > ht) { ht = ev2; hts = 2; }
+            } else {
+                ht = (j == 0) ? 0 : POA_NEG;
+            }
+            const int a1 = act ? ht + e1 * j : POA_IDENT;
+            const int a2 = act ? ht + e2 * j : POA_IDENT;
+            int i1 = a1, i2 = a2;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int u1 = __shfl_up(i1, d, 64), u2 = __shfl_up(i2, d, 64);
+                if (lane >= d) { i1 = u1 > i1 ? u1 : i1; i2 = u2 > i2 ? u2 : i2; }
+            }
+            if (lane == 63) {
+                sW1[buf * NW + wv] = i1; sW2[buf * NW + wv] = i2;
+                sL1[buf * NW + wv] = a1; sL2[buf * NW + wv] = a2;
+            }
+            POA_LDS_BARRIER();
+            int x1 = __shfl_up(i1, 1, 64), x2 = __shfl_up(i2, 1, 64);
+            int la1 = __shfl_up(a1, 1, 64), la2 = __shfl_up(a2, 1, 64);
+            if (lane == 0) {
+                x1 = POA_IDENT; x2 = POA_IDENT;
+                la1 = wv == 0 ? left1 : sL1[buf * NW + wv - 1];
+                la2 = wv == 0 ? left2 : sL2[buf * NW + wv - 1];
+            }
+            int pre1 = carry1, pre2 = carry2, all1 = carry1, all2 = carry2;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                const int t1 = sW1[buf * NW + q], t2 = sW2[buf * NW + q];
+                if (q < wv) { pre1 = t1 > pre1 ? t1 : pre1; pre2 = t2 > pre2 ? t2 : pre2; }
+                all1 = t1 > all1 ? t1 : all1;
+                all2 = t2 > all2 ? t2 : all2;
+            }
+            const int P1 = pre1 > x1 ? pre1 : x1;
+            const int P2 = pre2 > x2 ? pre2 : x2;
+            carry1 = all1; carry2 = all2;
+            left1 = sL1[buf * NW + NW - 1]; left2 = sL2[buf * NW + NW - 1];
+            int f1 = POA_NEG, f2 = POA_NEG, fo1 = 0, fo2 = 0;
+            if (j > beg) {
+                f1 = P1 - o1 - e1 * j;
+                f2 = P2 - o2 - e2 * j;
+                fo1 = P1 == la1;
+                fo2 = P2 == la2;
+            }
+            int h = ht, hs = hts;
+            if (f1 > h) { h = f1; hs = 3; }
+            if (f2 > h) { h = f2; hs = 4; }
+            if (act) {
+                const int lo4 = hs < 3 ? hs : 3 + (hs - 3) * 3 + hts;
+                const int code = lo4 | (fo1 << 4) | (fo2 << 5) | (of1 << 6) | (of2 << 7);
+                int dd1 = h - ev1; dd1 = dd1 < o1 ? dd1 : o1;
+                int dd2 = h - ev2; dd2 = dd2 < o2 ? dd2 : o2;
+                Hs[j] = h;
+                Ds[j] = (uint16_t)(dd1 | (dd2 << 8));
+                drow[c] = (uint8_t)code;
+                if (last) {
+                    Hrow[c] = h;
+                    d1row[c] = (uint8_t)dd1;
+                    d2row[c] = (uint8_t)dd2;
+                }
+                if (np > 1) {
+                    drow[(uint64_t)W + c] = (uint8_t)pm;
+                    drow[2ull * W + c] = (uint8_t)p1;
+                    drow[3ull * W + c] = (uint8_t)p2;
+                }
+                if (h > best) { best = h; lpos = j; rpos = j; }
+                else if (h == best) rpos = j;
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int ob = __shfl_xor(best, d, 64), ol = __shfl_xor(lpos, d, 64), orr = __shfl_xor(rpos, d, 64);
+            if (ob > best) { best = ob; lpos = ol; rpos = orr; }
+            else if (ob == best) { lpos = ol < lpos ? ol : lpos; rpos = orr > rpos ? orr : rpos; }
+        }
+        if (lane == 0) { sRed[wv * 3 + 0] = best; sRed[wv * 3 + 1] = lpos; sRed[wv * 3 + 2] = rpos; }
+        POA_LDS_BARRIER();  // row complete in LDS; also fences the scratch buffers between rows
+        best = sRed[0]; lpos = sRed[1]; rpos = sRed[2];
+#pragma unroll
+        for (int q = 1; q < NW; q++) {
+            const int ob = sRed[q * 3], ol = sRed[q * 3 + 1], orr = sRed[q * 3 + 2];
+            if (ob > best) { best = ob; lpos = ol; rpos = orr; }
+            else if (ob == best) { lpos = ol < lpos ? ol : lpos; rpos = orr > rpos ? orr : rpos; }
+        }
+        if (tid == 0) { vlmax[r] = lpos; vrmax[r] = rpos; }
+        prev_beg = beg; prev_end = end; prev_lmax = lpos; prev_rmax = rpos;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        out_cells[blockIdx.x] = cells;
+        out_vcells[blockIdx.x] = vcells;
+        if (failed) {
+            out_status[blockIdx.x] = POA_ST_POOL;
+            out_score[blockIdx.x] = POA_NEG;
+            out_row[blockIdx.x] = 0;
+        } else {
+            int bestv = INT32_MIN;
+            uint32_t brow = 0;
+            bool have = false;
+            for (uint32_t t = 0; t < pb.n_sink; t++) {
+                const uint32_t p = sink_preds[pb.sink0 + t];
+                const int bp = vbeg[p], ep = vend[p];
+                int val = POA_NEG;
+                if (qlen >= bp && qlen <= ep) val = ((const volatile int32_t *)(pool + vvoff[p]))[qlen - bp];
+                if (!have || val > bestv) { bestv = val; brow = p; have = true; }
+            }
+            out_score[blockIdx.x] = bestv;
+            out_row[blockIdx.x] = brow;
+            out_status[blockIdx.x] = (have && bestv > POA_NEG / 2) ? POA_ST_OK : POA_ST_NOALN;
+        }
+    }
+}
+
+static inline size_t poa_lds_bytes(uint32_t lds_cols, int nt)
+{
+    const int nw = nt / 64;
+    return ((7ull * lds_cols + 15ull) & ~15ull) + (size_t)(8 * nw + 3 * nw + 4) * 4 + 16;
+}
+
 // K4b: one lane per problem.  ops are written in reverse (sink -> source) order.
 __global__ __launch_bounds__(64) void k_poa_traceback(
-    uint32_t n, const poa_prob *__restrict__ probs, const uint8_t *__restrict__ row_flags,
-    const uint8_t *__restrict__ row_npred, const uint32_t *__restrict__ row_pred_start,
+    uint32_t n, const poa_prob *__restrict__ probs, const uint4 *__restrict__ row_meta,
     const uint32_t *__restrict__ preds, const int32_t *__restrict__ row_beg, const int32_t *__restrict__ row_end,
     const uint64_t *__restrict__ row_doff, const uint8_t *__restrict__ pool, const uint32_t *__restrict__ out_row,
     int32_t *__restrict__ out_status, uint8_t *__restrict__ ops, uint32_t *__restrict__ orow,
@@ -356,9 +674,10 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
     bool bad = false;
     while (i > 0 && !bad) {
         const uint64_t ri = pb.row0 + i;
-        const uint32_t flags = row_flags[ri];
+        const uint4 mt = row_meta[ri];
+        const uint32_t flags = (mt.x >> 8) & 255u;
         const bool first = (flags & POA_FLAG_FIRST) != 0;
-        const int np = first ? (int)row_npred[ri] : 1;
+        const int np = first ? (int)((mt.x >> 16) & 255u) : 1;
         const int beg = row_beg[ri], end = row_end[ri];
         const uint64_t W = (uint64_t)(end - beg + 1);
         const uint64_t doff = row_doff[ri];
@@ -372,13 +691,13 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
         if (nops + 1 >= cap) { bad = true; break; }
         if (src == 0) {
             const int t = np > 1 ? pool[doff + W + c] : 0;
-            const uint32_t p = first ? preds[pb.pred0 + row_pred_start[ri] + t] : i - 1;
+            const uint32_t p = first ? preds[pb.pred0 + mt.z + t] : i - 1;
             if (j < 1) { bad = true; break; }
             po[nops] = 0; pr[nops] = i; nops++;
             i = p; j -= 1; st = 0;
         } else if (src == 1 || src == 2) {
             const int t = np > 1 ? pool[doff + (src == 1 ? 2 : 3) * W + c] : 0;
-            const uint32_t p = first ? preds[pb.pred0 + row_pred_start[ri] + t] : i - 1;
+            const uint32_t p = first ? preds[pb.pred0 + mt.z + t] : i - 1;
             const int open = (code >> (src == 1 ? 6 : 7)) & 1;
             po[nops] = 2; pr[nops] = i; nops++;
             st = open ? 0 : src;
@@ -483,6 +802,20 @@ bool poa_prepare(const uint64_t *node_off, uint64_t n_nodes, const char *nodes_c
     return true;
 }
 
+struct poa_ws {
+    vga_dbuf<poa_prob> d_probs;
+    vga_dbuf<uint4> d_meta;
+    vga_dbuf<uint8_t> d_ops;
+    vga_dbuf<int32_t> d_beg, d_end, d_lmax, d_rmax, d_score, d_status;
+    vga_dbuf<uint32_t> d_preds, d_sink, d_row, d_orow, d_nops;
+    vga_dbuf<uint64_t> d_doff, d_voff, d_cells, d_vcells;
+    vga_dbuf<char> d_q;
+    vga_dbuf<unsigned long long> d_next;
+    uint8_t *pool = nullptr;
+    uint64_t pool_size = 0;
+    ~poa_ws() { if (pool) (void)hipFree(pool); }
+};
+
 template <typename T>
 T *pmalloc(size_t n)
 {
@@ -520,6 +853,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     (void)hipSetDevice(ctx->device);
     hipStream_t st = ctx->stream;
     auto t_host0 = std::chrono::steady_clock::now();
+    vga_trace tr("poa");
     if (params->gap_open1 < 0 || params->gap_open1 > 255 || params->gap_open2 < 0 || params->gap_open2 > 255 ||
         params->gap_ext1 < 0 || params->gap_ext2 < 0)
         return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "gap open penalties must be in 0..255");
@@ -582,6 +916,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
                                  (unsigned long long)p);
         }
 
+    tr.mark("row graphs (host threads)");
     // ---- flatten
     std::vector<poa_prob> probs(n);
     uint64_t tot_rows = 0, tot_preds = 0, tot_sink = 0, tot_q = 0, tot_ops = 0;
@@ -597,18 +932,15 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
         tot_ops += (uint64_t)G[p].N + G[p].qlen + 2;
         res->n_rows[p] = G[p].N;
     }
-    std::vector<uint8_t> h_base(tot_rows), h_flags(tot_rows), h_npred(tot_rows);
-    std::vector<int32_t> h_remain(tot_rows);
-    std::vector<uint32_t> h_pstart(tot_rows), h_preds(tot_preds ? tot_preds : 1), h_sink(tot_sink ? tot_sink : 1);
+    std::vector<uint4> h_meta(tot_rows);
+    std::vector<uint32_t> h_preds(tot_preds ? tot_preds : 1), h_sink(tot_sink ? tot_sink : 1);
     std::vector<char> h_q(tot_q ? tot_q : 1);
     for (uint64_t p = 0; p < n; p++) {
         const poa_prob &pb = probs[p];
         const poa_graph_host &g = G[p];
-        memcpy(&h_base[pb.row0], g.base.data(), g.N + 1);
-        memcpy(&h_flags[pb.row0], g.flags.data(), g.N + 1);
-        memcpy(&h_npred[pb.row0], g.npred.data(), g.N + 1);
-        memcpy(&h_remain[pb.row0], g.remain.data(), (g.N + 1) * 4ull);
-        memcpy(&h_pstart[pb.row0], g.pred_start.data(), (g.N + 1) * 4ull);
+        for (uint32_t r = 0; r <= g.N; r++)
+            h_meta[pb.row0 + r] = make_uint4((uint32_t)g.base[r] | ((uint32_t)g.flags[r] << 8) | ((uint32_t)g.npred[r] << 16),
+                                             (uint32_t)g.remain[r], g.pred_start[r], 0u);
         if (!g.preds.empty()) memcpy(&h_preds[pb.pred0], g.preds.data(), g.preds.size() * 4);
         if (!g.sink.empty()) memcpy(&h_sink[pb.sink0], g.sink.data(), g.sink.size() * 4);
         if (g.qlen) memcpy(&h_q[pb.q0], queries_concat + query_off[p], g.qlen);
@@ -624,15 +956,18 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
         }                                                                                            \
     } while (0)
 
-    vga_dbuf<poa_prob> d_probs;
-    vga_dbuf<uint8_t> d_base, d_flags, d_npred, d_ops;
-    vga_dbuf<int32_t> d_remain, d_beg, d_end, d_lmax, d_rmax, d_score, d_status;
-    vga_dbuf<uint32_t> d_pstart, d_preds, d_sink, d_row, d_orow, d_nops;
-    vga_dbuf<uint64_t> d_doff, d_voff, d_cells, d_vcells;
-    vga_dbuf<char> d_q;
-    vga_dbuf<unsigned long long> d_next;
-    POA_CHECK(d_probs.reserve(n)); POA_CHECK(d_base.reserve(tot_rows)); POA_CHECK(d_flags.reserve(tot_rows));
-    POA_CHECK(d_npred.reserve(tot_rows)); POA_CHECK(d_remain.reserve(tot_rows)); POA_CHECK(d_pstart.reserve(tot_rows));
+    tr.mark("flatten");
+    if (!ctx->poa_ws) {
+        ctx->poa_ws = new poa_ws();
+        ctx->poa_ws_free = [](void *q) { delete (poa_ws *)q; };
+    }
+    poa_ws &W_ = *(poa_ws *)ctx->poa_ws;
+    auto &d_probs = W_.d_probs; auto &d_meta = W_.d_meta; auto &d_ops = W_.d_ops;
+    auto &d_beg = W_.d_beg; auto &d_end = W_.d_end; auto &d_lmax = W_.d_lmax; auto &d_rmax = W_.d_rmax;
+    auto &d_score = W_.d_score; auto &d_status = W_.d_status; auto &d_preds = W_.d_preds;
+    auto &d_sink = W_.d_sink; auto &d_row = W_.d_row; auto &d_orow = W_.d_orow; auto &d_nops = W_.d_nops; auto &d_doff = W_.d_doff;
+    auto &d_voff = W_.d_voff; auto &d_cells = W_.d_cells; auto &d_vcells = W_.d_vcells; auto &d_q = W_.d_q; auto &d_next = W_.d_next;
+    POA_CHECK(d_probs.reserve(n)); POA_CHECK(d_meta.reserve(tot_rows));
     POA_CHECK(d_preds.reserve(h_preds.size())); POA_CHECK(d_sink.reserve(h_sink.size())); POA_CHECK(d_q.reserve(h_q.size()));
     POA_CHECK(d_beg.reserve(tot_rows)); POA_CHECK(d_end.reserve(tot_rows)); POA_CHECK(d_doff.reserve(tot_rows));
     POA_CHECK(d_voff.reserve(tot_rows)); POA_CHECK(d_lmax.reserve(tot_rows)); POA_CHECK(d_rmax.reserve(tot_rows));
@@ -640,36 +975,14 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     POA_CHECK(d_ops.reserve(tot_ops)); POA_CHECK(d_orow.reserve(tot_ops)); POA_CHECK(d_nops.reserve(n));
     POA_CHECK(d_next.reserve(1));
     POA_CHECK(hipMemcpyAsync(d_probs.p, probs.data(), n * sizeof(poa_prob), hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(d_base.p, h_base.data(), tot_rows, hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(d_flags.p, h_flags.data(), tot_rows, hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(d_npred.p, h_npred.data(), tot_rows, hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(d_remain.p, h_remain.data(), tot_rows * 4, hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(d_pstart.p, h_pstart.data(), tot_rows * 4, hipMemcpyHostToDevice, st));
+    POA_CHECK(hipMemcpyAsync(d_meta.p, h_meta.data(), tot_rows * sizeof(uint4), hipMemcpyHostToDevice, st));
     POA_CHECK(hipMemcpyAsync(d_preds.p, h_preds.data(), h_preds.size() * 4, hipMemcpyHostToDevice, st));
     POA_CHECK(hipMemcpyAsync(d_sink.p, h_sink.data(), h_sink.size() * 4, hipMemcpyHostToDevice, st));
     POA_CHECK(hipMemcpyAsync(d_q.p, h_q.data(), h_q.size(), hipMemcpyHostToDevice, st));
 
-    // ---- pool: as much HBM as is free (minus a margin); problems run in sub-batches that fit it
-    size_t free_b = 0, total_b = 0;
-    POA_CHECK(hipMemGetInfo(&free_b, &total_b));
-    uint64_t pool_size = (uint64_t)(free_b * 0.85);
-    const char *env_pool = getenv("VGA_POOL_BYTES");
-    if (env_pool) pool_size = std::min<uint64_t>(pool_size, strtoull(env_pool, nullptr, 10));
-    pool_size &= ~(POA_CHUNK - 1);
-    if (pool_size < 64 * POA_CHUNK) {
-        vga_poa_result_free(res);
-        return vga_set_error(ctx, VGA_ERR_NOMEM, "vga_poa_batch: only %llu bytes of HBM free for the traceback pool",
-                             (unsigned long long)free_b);
-    }
-    uint8_t *d_pool = nullptr;
-    POA_CHECK(hipMalloc((void **)&d_pool, pool_size));
-
-    poa_dev_params P;
-    P.match = params->match; P.mismatch = params->mismatch; P.o1 = params->gap_open1; P.e1 = params->gap_ext1;
-    P.o2 = params->gap_open2; P.e2 = params->gap_ext2; P.banded = params->wb >= 0;
-
-    // Sub-batch sizing: a problem's pool use is unknown before it runs (the band is adaptive), so
-    // estimate generously and shrink on POA_ST_POOL.
+    tr.mark("reserve + H2D enqueue");
+    // ---- pool: persistent in the ctx, sized for this batch's estimated need (capped by free HBM) and only
+    // ever grown.  Problems run in sub-batches that fit it.
     auto est_bytes = [&](uint64_t p) -> uint64_t {
         const poa_graph_host &g = G[p];
         uint64_t w = params->wb < 0 ? g.qlen : (uint64_t)params->wb + (uint64_t)(params->wf * (double)g.qlen);
@@ -678,6 +991,36 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
         uint64_t width = std::min<uint64_t>((uint64_t)g.qlen + 1, 2 * w + 1 + (uint64_t)excess + 64);
         return (uint64_t)((double)g.N * (double)width * 2.6) + 4 * POA_CHUNK;
     };
+    {
+        uint64_t want = 0, biggest = 0;
+        for (uint64_t p = 0; p < n; p++) { uint64_t e = est_bytes(p); want += e; biggest = std::max(biggest, e); }
+        want = (uint64_t)((double)want * 1.15) + 64 * POA_CHUNK;
+        const char *env_pool = getenv("VGA_POOL_BYTES");
+        if (env_pool) want = std::min<uint64_t>(want, strtoull(env_pool, nullptr, 10));
+        if (W_.pool_size < want) {
+            size_t free_b = 0, total_b = 0;
+            POA_CHECK(hipMemGetInfo(&free_b, &total_b));
+            uint64_t avail = (uint64_t)((double)(free_b + W_.pool_size) * 0.85);
+            uint64_t target = std::min(want, avail) & ~(POA_CHUNK - 1);
+            if (target > W_.pool_size) {
+                if (W_.pool) { (void)hipFree(W_.pool); W_.pool = nullptr; W_.pool_size = 0; }
+                if (target < 64 * POA_CHUNK) {
+                    vga_poa_result_free(res);
+                    return vga_set_error(ctx, VGA_ERR_NOMEM, "vga_poa_batch: only %llu bytes of HBM free for the traceback pool",
+                                         (unsigned long long)free_b);
+                }
+                POA_CHECK(hipMalloc((void **)&W_.pool, target));
+                W_.pool_size = target;
+            }
+        }
+    }
+    uint8_t *d_pool = W_.pool;
+    const uint64_t pool_size = W_.pool_size;
+    tr.mark("pool hipMalloc");
+    poa_dev_params P;
+    P.match = params->match; P.mismatch = params->mismatch; P.o1 = params->gap_open1; P.e1 = params->gap_ext1;
+    P.o2 = params->gap_open2; P.e2 = params->gap_ext2; P.banded = params->wb >= 0;
+
     std::vector<int32_t> h_status(n), h_score(n);
     std::vector<uint32_t> h_row(n), h_nops(n);
     std::vector<uint64_t> h_cells(n), h_vcells(n);
@@ -700,14 +1043,44 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
         POA_CHECK(hipMemsetAsync(d_next.p, 0, sizeof(unsigned long long), st));
         int t_dp = vga_timer_begin(ctx, "poa_band_dp", 0);
         POA_CHECK(hipMemcpyAsync(d_probs.p + p0, probs.data() + p0, nb * sizeof(poa_prob), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_poa_dp<256>, dim3(nb), dim3(256), 0, st, d_probs.p + p0, d_q.p, d_base.p, d_flags.p, d_npred.p,
-                           d_remain.p, d_pstart.p, d_preds.p, d_sink.p, P, d_beg.p, d_end.p, d_doff.p, d_voff.p, d_lmax.p,
-                           d_rmax.p, d_pool, d_next.p, pool_size, d_score.p + p0, d_row.p + p0, d_status.p + p0,
-                           d_cells.p + p0, d_vcells.p + p0);
+        {
+            uint32_t max_q = 0;
+            for (uint64_t p = p0; p < p1; p++) max_q = std::max(max_q, G[p].qlen);
+            const uint32_t lds_cols = max_q + 1;
+            const char *force = getenv("VGA_POA_KERNEL");  // "gmem" | "lds256" | "lds512" | "lds1024" (testing)
+            int nt = max_q >= 1536 ? 512 : 256;
+            bool use_lds = poa_lds_bytes(lds_cols, nt) <= 160 * 1024 - 256;
+            if (force) {
+                if (!strcmp(force, "gmem")) use_lds = false;
+                else if (!strcmp(force, "lds256")) nt = 256;
+                else if (!strcmp(force, "lds512")) nt = 512;
+                else if (!strcmp(force, "lds1024")) nt = 1024;
+                if (strcmp(force, "gmem") && poa_lds_bytes(lds_cols, nt) > 160 * 1024 - 256) use_lds = false;
+            }
+#define POA_ARGS d_probs.p + p0, d_q.p, d_meta.p, d_preds.p, d_sink.p, P, d_beg.p, \
+                 d_end.p, d_doff.p, d_voff.p, d_lmax.p, d_rmax.p, d_pool, d_next.p, pool_size, d_score.p + p0, d_row.p + p0,        \
+                 d_status.p + p0, d_cells.p + p0, d_vcells.p + p0
+            if (!use_lds) {
+                hipLaunchKernelGGL(k_poa_dp<256>, dim3(nb), dim3(256), 0, st, POA_ARGS);
+            } else {
+                const size_t lds = poa_lds_bytes(lds_cols, nt);
+                if (nt == 256) {
+                    POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(k_poa_dp_lds<256>, dim3(nb), dim3(256), lds, st, POA_ARGS, lds_cols);
+                } else if (nt == 512) {
+                    POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(k_poa_dp_lds<512>, dim3(nb), dim3(512), lds, st, POA_ARGS, lds_cols);
+                } else {
+                    POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(k_poa_dp_lds<1024>, dim3(nb), dim3(1024), lds, st, POA_ARGS, lds_cols);
+                }
+            }
+#undef POA_ARGS
+            POA_CHECK(hipGetLastError());
+        }
         vga_timer_end(ctx, t_dp);
         int t_tb = vga_timer_begin(ctx, "poa_traceback", 0);
-        hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, d_probs.p + p0, d_flags.p, d_npred.p,
-                           d_pstart.p, d_preds.p, d_beg.p, d_end.p, d_doff.p, d_pool, d_row.p + p0, d_status.p + p0, d_ops.p,
+        hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, d_probs.p + p0, d_meta.p, d_preds.p, d_beg.p, d_end.p, d_doff.p, d_pool, d_row.p + p0, d_status.p + p0, d_ops.p,
                            d_orow.p, d_nops.p + p0);
         vga_timer_end(ctx, t_tb);
         POA_CHECK(hipMemcpyAsync(h_status.data() + p0, d_status.p + p0, nb * 4, hipMemcpyDeviceToHost, st));
@@ -722,9 +1095,9 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
         }
         p0 = p1;
     }
+    tr.mark("dp + traceback (sub-batches)");
     vga_timer_end(ctx, t_total);
     if (rc_final != VGA_OK) {
-        (void)hipFree(d_pool);
         vga_poa_result_free(res);
         return vga_set_error(ctx, rc_final, "vga_poa_batch: a single problem does not fit the %llu byte traceback pool",
                              (unsigned long long)pool_size);
@@ -737,7 +1110,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     POA_CHECK(hipMemcpyAsync(h_ops.data(), d_ops.p, tot_ops, hipMemcpyDeviceToHost, st));
     POA_CHECK(hipMemcpyAsync(h_orow.data(), d_orow.p, tot_ops * 4, hipMemcpyDeviceToHost, st));
     POA_CHECK(hipStreamSynchronize(st));
-    (void)hipFree(d_pool);
+    tr.mark("D2H ops");
     vga_timers_collect(ctx);
 
     // ---- host: CIGAR / cs / node path from the raw op stream (reverse order on the device)
@@ -808,6 +1181,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
             });
         for (auto &x : th) x.join();
     }
+    tr.mark("cigar/cs (host threads)");
     uint64_t tp = 0, tc = 0, ts = 0;
     for (uint64_t p = 0; p < n; p++) {
         res->path_off[p] = tp; res->cigar_off[p] = tc; res->cs_off[p] = ts;
@@ -841,6 +1215,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
         if (a.name == "poa_traceback") a.bytes = 6 * all_ops;
     }
 #undef POA_CHECK
+    tr.mark("pack results");
     *out = res;
     return VGA_OK;
 }
