@@ -62,7 +62,7 @@ def main():
 
     # ---- workload: identical generator on every rank, different seed per rank (different reads, same shape)
     t0 = time.time()
-    reads = pkg.readsim.simulate_reads(GFA, args.reads, args.read_len, 0.03, 0.03, 0.04, seed=77 + rank)
+    reads = pkg.readsim.simulate_reads(GFA, args.reads, args.read_len, 0.03, 0.03, 0.04, seed=pkg.sharding.bench_seed(rank))
     seqs = [r.seq for r in reads]
     t_gen = time.time() - t0
 
@@ -94,15 +94,8 @@ def main():
             e["bytes"] += k["algorithmic_bytes"]
     barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([last["aligned"], last["n_reads"]], dtype=torch.float64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        aligned_all, reads_all = float(cnt[0].item()), float(cnt[1].item())
-    else:
-        aligned_all, reads_all = float(last["aligned"]), float(last["n_reads"])
+    elapsed, aligned_all, reads_all = pkg.sharding.reduce_timing(elapsed, last["aligned"], last["n_reads"], world,
+                                                                 device="cuda" if world > 1 else None)
 
     if rank != 0:
         if world > 1:
