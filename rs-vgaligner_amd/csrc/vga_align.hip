@@ -11,6 +11,7 @@
 // device is listed under "next" in DESIGN.md.  The ./subgraphs/*.gfa export side effect of
 // align.rs:104-111 is a debugging aid and is not reproduced.
 #include "vga_common.hpp"
+#include "vga_poa_internal.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -206,6 +207,7 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
     const uint64_t R = b->n_reads;
     const uint32_t k = ctx->index.k;
     auto t0 = std::chrono::steady_clock::now();
+    vga_trace tr("align");
 
     // ---- which (read, chain) pairs become POA problems: first min(best_n, len) chains (align.rs:43-50)
     std::vector<uint64_t> prob_read, prob_chain;
@@ -241,43 +243,22 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
         for (auto &x : th) x.join();
     }
     auto t1 = std::chrono::steady_clock::now();
+    tr.mark("subgraphs (host threads)");
 
-    // ---- flatten into the create_align_safe batch form.  Node strings of consecutive problems are laid
-    // out back to back, so node_off needs only one trailing end offset for the whole batch.
-    std::vector<uint64_t> edge_ptr(n + 1, 0), query_off(n + 1, 0), nptr(n + 1, 0), noff;
-    uint64_t tot_edges = 0, tot_seq = 0, tot_q = 0;
+    // ---- the create_align_safe problems, by reference into the subgraphs (no copy)
+    std::vector<poa_view> views(n);
     for (uint64_t p = 0; p < n; p++) {
-        edge_ptr[p] = tot_edges; query_off[p] = tot_q;
-        tot_edges += SG[p].esrc.size();
-        tot_seq += SG[p].seqs.size();
-        tot_q += b->read_off[prob_read[p] + 1] - b->read_off[prob_read[p]];
-    }
-    edge_ptr[n] = tot_edges; query_off[n] = tot_q;
-    std::string nodes_concat;
-    nodes_concat.reserve(tot_seq);
-    std::vector<uint32_t> esrc, edst;
-    esrc.reserve(tot_edges); edst.reserve(tot_edges);
-    std::string queries;
-    queries.reserve(tot_q);
-    for (uint64_t p = 0; p < n; p++) {
-        nptr[p] = noff.size();
-        const uint64_t base = nodes_concat.size();
-        for (size_t v = 0; v < SG[p].handles.size(); v++) noff.push_back(base + SG[p].node_off[v]);
-        nodes_concat += SG[p].seqs;
-        esrc.insert(esrc.end(), SG[p].esrc.begin(), SG[p].esrc.end());
-        edst.insert(edst.end(), SG[p].edst.begin(), SG[p].edst.end());
         const uint64_t r = prob_read[p];
-        queries.append(b->reads.data() + b->read_off[r], b->read_off[r + 1] - b->read_off[r]);
+        views[p] = {SG[p].node_off.data(), SG[p].seqs.data(), SG[p].handles.size(), SG[p].esrc.data(), SG[p].edst.data(),
+                    SG[p].esrc.size(), b->reads.data() + b->read_off[r], (uint32_t)(b->read_off[r + 1] - b->read_off[r])};
     }
-    nptr[n] = noff.size();
-    noff.push_back(nodes_concat.size());
-
-    vga_poa_result *pr = nullptr;
+    std::vector<poa_item> items;
+    poa_timing tm;
     if (n > 0) {
-        int rc = vga_poa_batch(ctx, n, nptr.data(), noff.data(), nodes_concat.data(), edge_ptr.data(), esrc.data(), edst.data(),
-                               query_off.data(), queries.data(), params, &pr);
+        int rc = poa_run(ctx, views, params, items, tm);
         if (rc != VGA_OK) return rc;
     }
+    tr.mark("poa_run");
 
     // ---- per read: keep the candidate with the longest path (stable, align.rs:52-54)
     vga_align_result *res = (vga_align_result *)calloc(1, sizeof(vga_align_result));
@@ -292,66 +273,64 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
     res->cigar_off = amalloc<uint64_t>(R + 1);
     res->cs_off = amalloc<uint64_t>(R + 1);
     std::vector<int64_t> pick(R, -1);
-    uint64_t tp = 0, tc = 0, ts = 0;
-    std::vector<std::vector<uint64_t>> paths(R);
+    std::vector<uint32_t> path_n(R, 0);
     for (uint64_t r = 0; r < R; r++) {
         int64_t best = -1;
         for (uint64_t p = read_prob0[r]; p < read_prob0[r + 1]; p++) {
-            if (!pr->ok[p]) continue;
-            uint64_t plen = pr->path_off[p + 1] - pr->path_off[p];
-            if (best < 0 || plen > pr->path_off[best + 1] - pr->path_off[best]) best = (int64_t)p;
+            if (!items[p].ok) continue;
+            if (best < 0 || items[p].rows.size() > items[best].rows.size()) best = (int64_t)p;
         }
         pick[r] = best;
-        res->aligned[r] = best >= 0;
-        res->path_off[r] = tp; res->cigar_off[r] = tc; res->cs_off[r] = ts;
-        res->path_length[r] = res->path_start[r] = res->path_end[r] = res->block_length[r] = 0;
-        res->best_score[r] = 0;
         if (best >= 0) {
-            const uint64_t p = (uint64_t)best;
-            // graph_nodes.dedup() -> range.handles[idx] (align.rs:1107-1123)
-            uint32_t prev = 0xFFFFFFFFu;
-            for (uint64_t t = pr->path_off[p]; t < pr->path_off[p + 1]; t++) {
-                uint32_t gn = pr->graph_nodes[t];
-                if (t > pr->path_off[p] && gn == prev) continue;
-                prev = gn;
-                paths[r].push_back(SG[p].handles[gn]);
-            }
-            tp += paths[r].size();
-            tc += pr->cigar_off[p + 1] - pr->cigar_off[p];
-            ts += pr->cs_off[p + 1] - pr->cs_off[p];
-            res->path_length[r] = (uint32_t)(pr->path_off[p + 1] - pr->path_off[p]);
-            res->path_start[r] = pr->aln_start_offset[p];
-            res->path_end[r] = pr->aln_end_offset[p];
-            res->block_length[r] = pr->n_aligned_bases[p];
-            res->best_score[r] = pr->best_score[p];
-        } else {
-            tc += 1; ts += 1;
+            // graph_nodes.dedup() (align.rs:1114): count the runs
+            const std::vector<uint32_t> &gn = items[best].gnodes;
+            uint32_t c = 0;
+            for (size_t t = 0; t < gn.size(); t++) c += (t == 0 || gn[t] != gn[t - 1]);
+            path_n[r] = c;
         }
+    }
+    uint64_t tp = 0, tc = 0, ts = 0;
+    for (uint64_t r = 0; r < R; r++) {
+        res->path_off[r] = tp; res->cigar_off[r] = tc; res->cs_off[r] = ts;
+        tp += path_n[r];
+        tc += pick[r] >= 0 ? items[pick[r]].cigar.size() + 1 : 1;
+        ts += pick[r] >= 0 ? items[pick[r]].cs.size() + 1 : 1;
     }
     res->path_off[R] = tp; res->cigar_off[R] = tc; res->cs_off[R] = ts;
     res->path_handles = amalloc<uint64_t>(tp);
     res->cigar = amalloc<char>(tc);
     res->cs = amalloc<char>(ts);
     for (uint64_t r = 0; r < R; r++) {
-        for (size_t t = 0; t < paths[r].size(); t++) res->path_handles[res->path_off[r] + t] = paths[r][t];
-        if (pick[r] >= 0) {
-            const uint64_t p = (uint64_t)pick[r];
-            memcpy(res->cigar + res->cigar_off[r], pr->cigar + pr->cigar_off[p], pr->cigar_off[p + 1] - pr->cigar_off[p]);
-            memcpy(res->cs + res->cs_off[r], pr->cs + pr->cs_off[p], pr->cs_off[p + 1] - pr->cs_off[p]);
-        } else {
+        res->aligned[r] = pick[r] >= 0;
+        res->path_length[r] = res->path_start[r] = res->path_end[r] = res->block_length[r] = 0;
+        res->best_score[r] = 0;
+        if (pick[r] < 0) {
             res->cigar[res->cigar_off[r]] = 0;
             res->cs[res->cs_off[r]] = 0;
+            continue;
         }
+        const uint64_t p = (uint64_t)pick[r];
+        const poa_item &it = items[p];
+        uint64_t o = res->path_off[r];
+        for (size_t t = 0; t < it.gnodes.size(); t++)
+            if (t == 0 || it.gnodes[t] != it.gnodes[t - 1]) res->path_handles[o++] = SG[p].handles[it.gnodes[t]];  // align.rs:1120-1123
+        res->path_length[r] = (uint32_t)it.rows.size();
+        res->path_start[r] = it.start_off;
+        res->path_end[r] = it.end_off;
+        res->block_length[r] = it.aligned;
+        res->best_score[r] = it.score;
+        memcpy(res->cigar + res->cigar_off[r], it.cigar.c_str(), it.cigar.size() + 1);
+        memcpy(res->cs + res->cs_off[r], it.cs.c_str(), it.cs.size() + 1);
     }
     res->poa_problems = n;
     for (uint64_t p = 0; p < n; p++) {
-        res->poa_rows += pr->n_rows[p]; res->poa_cells += pr->n_cells[p]; res->poa_value_cells += pr->n_value_cells[p];
+        res->poa_rows += items[p].n_rows; res->poa_cells += items[p].n_cells; res->poa_value_cells += items[p].n_vcells;
     }
     res->ms_subgraph = (float)std::chrono::duration<double, std::milli>(t1 - t0).count();
-    res->ms_dp = pr ? pr->ms_dp : 0.f;
-    res->ms_traceback = pr ? pr->ms_traceback : 0.f;
+    res->ms_dp = tm.ms_dp;
+    res->ms_traceback = tm.ms_tb;
     res->ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    vga_poa_result_free(pr);
+    tr.mark("assemble records");
     *out = res;
     return VGA_OK;
 }

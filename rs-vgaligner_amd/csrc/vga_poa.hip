@@ -2,27 +2,29 @@
 // native component, abPOA behind  AbpoaAligner::create_align_safe(nodes, edges, query, Global)
 // (src/align.rs:173-203; result fields consumed at src/align.rs:1107,1152-1165).
 //
-//   K4  k_poa_dp<NT>     one workgroup per (read, subgraph) problem.  Rows = graph bases in
-//                        topological order, processed one after the other because the adaptive band
-//                        of a row depends on where its predecessors' maxima fell (that dependency is
-//                        also why an anti-diagonal wavefront cannot be used: a row's band is unknown
-//                        until its predecessor rows are complete).  Lanes run across the band's
-//                        columns, NT per step, all accesses coalesced.  The in-row insertion
-//                        recurrence is a max-plus prefix scan (wave shuffles + one LDS exchange).
+//   K4  k_poa_dp_lds<NT,4>  one workgroup per (read, subgraph) problem.  Rows = graph bases in topological
+//                        order, processed one after the other because the adaptive band of a row depends on
+//                        where its predecessors' maxima fell (that dependency is also why an anti-diagonal
+//                        wavefront cannot be used: a row's band is unknown until the rows above are complete).
+//                        Lanes run across the band's columns, four adjacent columns per lane.
 //   K4b k_poa_traceback  one lane per problem walking the 1-byte direction codes.
 //
-// HBM layout per problem (all carved from one pool by a bump allocator, 1 MiB chunks):
-//   direction row  : 1 byte per cell (+3 predecessor-choice bytes per cell on the rare rows with
-//                    more than one predecessor) -- the only per-cell data kept for the traceback;
-//   value row      : int32 H + two 1-byte clamped gap deltas per cell, kept only for the LAST base of
-//                    every graph node (the only rows a later, non-adjacent row can depend on);
-//   ping-pong rows : the same 6 B/cell format for "previous row" hand-over inside a node.
-// The deltas: a successor only ever needs max(H - (O+E), Ek - E); storing d = min(H - Ek, O) keeps
-// exactly that quantity (H - E - d) and the open/extend decision (d == O) in one byte.
+// HBM layout per problem (all carved from one persistent pool by a device-side bump allocator, 1 MiB chunks;
+// every row is stored from the 4-aligned column  bal = beg & ~3  with a width rounded up to 4):
+//   direction row  : 1 byte per cell (+3 predecessor-choice bytes per cell on the rare rows with more than one
+//                    predecessor) -- the only per-cell data kept for the traceback;
+//   value row      : int32 H + two 1-byte clamped gap deltas per cell, kept only for the LAST base of every graph
+//                    node (the only rows a later, non-adjacent row can depend on) and the source row;
+//   row arrays     : 40 B per row (beg, end, direction offset, value offset, leftmost/rightmost max column,
+//                    predecessor-list slice).
+// The deltas: a successor only ever needs max(H - (O+E), Ek - E); storing d = min(H - Ek, O) keeps exactly that
+// quantity (H - E - d) and the open/extend decision (d == O) in one byte.
 //
-// Numerics are 32-bit integer and bit-exact against oracle/og_poa.c (see its header for the
+// Host -> device description of a problem is per NODE (16 B each) plus the node sequences; rows are generated
+// on the device.  Numerics are 32-bit integer and bit-exact against oracle/og_poa.c (see its header for the
 // specification: recurrences, tie order, band rule).
 #include "vga_common.hpp"
+#include "vga_poa_internal.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -31,8 +33,6 @@
 #define POA_NEG (-(1 << 29))
 #define POA_IDENT (INT32_MIN / 2)
 #define POA_CHUNK (1ull << 20)
-#define POA_FLAG_LAST 1u
-#define POA_FLAG_FIRST 2u
 
 #define POA_ST_OK 0
 #define POA_ST_POOL 1
@@ -40,15 +40,19 @@
 #define POA_ST_TRACE 3
 
 struct poa_prob {
-    uint64_t row0;   // first entry of the per-row arrays (rows 0..N)
-    uint64_t pred0;  // first entry of the predecessor list
+    uint64_t node0;  // first entry of the node table (entry 0 of a problem is the virtual source)
+    uint64_t pred0;  // first entry of the predecessor list (row ids)
     uint64_t sink0;  // first entry of the sink predecessor list
     uint64_t q0;     // first query byte
     uint64_t ops0;   // first entry of the traceback output
+    uint64_t row0;   // first entry of the per-row arrays (rows 0..N)
+    uint64_t seq0;   // first byte of the node sequences (row r is byte r-1)
     uint32_t n_sink;
     uint32_t qlen;
     uint32_t N;
     uint32_t w;      // adaptive band half-width: wb + floor(wf * qlen), computed on the host in double
+    uint32_t n_nodes;  // node-table entries incl. the source
+    uint32_t pad;
 };
 
 struct poa_dev_params {
@@ -63,320 +67,75 @@ __device__ __forceinline__ int poa_sub(const poa_dev_params &P, uint8_t g, uint8
     return g == q ? P.match : -P.mismatch;
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT) void k_poa_dp(
-    const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ row_meta,
-    const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds, poa_dev_params P,
-    int32_t *row_beg, int32_t *row_end, uint64_t *row_doff, uint64_t *row_voff, int32_t *row_lmax, int32_t *row_rmax,
-    uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size, int32_t *__restrict__ out_score,
-    uint32_t *__restrict__ out_row, int32_t *__restrict__ out_status, uint64_t *__restrict__ out_cells,
-    uint64_t *__restrict__ out_vcells)
-{
-    constexpr int NW = NT / 64;
-    __shared__ int32_t sA1[2][NT + 1];
-    __shared__ int32_t sA2[2][NT + 1];
-    __shared__ int32_t sW1[2][NW];
-    __shared__ int32_t sW2[2][NW];
-    __shared__ int32_t sRed[NW][3];
-    __shared__ unsigned long long s_alloc;
-
-    const poa_prob pb = probs[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int qlen = (int)pb.qlen;
-    const char *query = queries + pb.q0;
-    const uint4 *rmeta = row_meta + pb.row0;  // {base | flags << 8 | npred << 16, remain, pred_start, -}: one scalar load per row
-    const uint32_t *plist = preds + pb.pred0;
-    volatile int32_t *vbeg = row_beg + pb.row0;
-    volatile int32_t *vend = row_end + pb.row0;
-    volatile uint64_t *vvoff = row_voff + pb.row0;
-    volatile int32_t *vlmax = row_lmax + pb.row0;
-    volatile int32_t *vrmax = row_rmax + pb.row0;
-    uint64_t *gdoff = row_doff + pb.row0;
-
-    const int o1 = P.o1, e1 = P.e1, o2 = P.o2, e2 = P.e2;
-    const int bw = (int)pb.w;
-
-    // ---- bump allocation out of the pool (uniform control flow; thread 0 takes the chunk)
-    uint64_t dcur = 0, dend = 0, vcur = 0, vendp = 0;
-    bool failed = false;
-    auto take_chunk = [&](uint64_t &cur, uint64_t &end) {
-        __syncthreads();
-        if (tid == 0) s_alloc = atomicAdd(pool_next, (unsigned long long)POA_CHUNK);
-        __syncthreads();
-        uint64_t b = s_alloc;
-        if (b + POA_CHUNK > pool_size) failed = true;
-        cur = b;
-        end = b + POA_CHUNK;
-    };
-    auto alloc = [&](uint64_t &cur, uint64_t &end, uint64_t bytes) -> uint64_t {
-        bytes = (bytes + 15ull) & ~15ull;
-        if (cur + bytes > end) take_chunk(cur, end);
-        uint64_t r = cur;
-        cur += bytes;
-        return r;
-    };
-
-    const uint64_t pp_bytes = 6ull * (uint64_t)(qlen + 1);
-    uint64_t pp[2];
-    pp[0] = alloc(vcur, vendp, pp_bytes);
-    pp[1] = alloc(vcur, vendp, pp_bytes);
-
-    int prev_beg = 0, prev_end = 0, prev_lmax = 0, prev_rmax = 0;
-    uint64_t prev_voff = 0;
-    uint64_t cells = 0, vcells = 0;
-
-    for (uint32_t r = 0; r <= pb.N && !failed; r++) {
-        const uint4 mt = rmeta[r];
-        const uint32_t flags = (mt.x >> 8) & 255u;
-        const bool first = (flags & POA_FLAG_FIRST) != 0;
-        const bool last = (flags & POA_FLAG_LAST) != 0;
-        const int np = r == 0 ? 0 : (first ? (int)((mt.x >> 16) & 255u) : 1);
-        const uint32_t ps = mt.z;
-        // ---- band (abPOA adaptive band; pulls what the predecessors' maxima pushed)
-        int mpl, mpr;
-        if (r == 0) { mpl = 0; mpr = 0; }
-        else if (!first) { mpl = prev_lmax + 1; mpr = prev_rmax + 1; }
-        else {
-            mpl = INT32_MAX; mpr = 0;
-            for (int t = 0; t < np; t++) {
-                const uint32_t p = plist[ps + t];
-                const int lm = vlmax[p] + 1, rm = vrmax[p] + 1;
-                mpl = lm < mpl ? lm : mpl;
-                mpr = rm > mpr ? rm : mpr;
-            }
-        }
-        int beg, end;
-        if (!P.banded) { beg = 0; end = qlen; }
-        else {
-            const int diag = qlen - (int)mt.y;
-            const int lo = mpl < diag ? mpl : diag;
-            const int hi = mpr > diag ? mpr : diag;
-            beg = lo - bw; if (beg < 0) beg = 0;
-            end = hi + bw; if (end > qlen) end = qlen;
-        }
-        const int W = end - beg + 1;
-        if (r > 0) cells += (uint64_t)W;
-        if (last) vcells += (uint64_t)W;
-        const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u));
-        if (failed) break;
-        uint64_t voff;
-        if (last) { voff = alloc(vcur, vendp, 6ull * (uint64_t)W); if (failed) break; }
-        else voff = pp[r & 1u];
-        if (tid == 0) {
-            vbeg[r] = beg;
-            vend[r] = end;
-            gdoff[r] = doff;
-            vvoff[r] = voff;
-        }
-        int32_t *Hrow = (int32_t *)(pool + voff);
-        uint8_t *d1row = pool + voff + 4ull * (uint64_t)W;
-        uint8_t *d2row = d1row + W;
-        uint8_t *drow = pool + doff;
-        const uint8_t gb = (uint8_t)(mt.x & 255u);
-
-        int carry1 = POA_IDENT, carry2 = POA_IDENT, left1 = POA_IDENT, left2 = POA_IDENT;
-        int best = INT32_MIN, lpos = beg, rpos = beg;
-        int buf = 0;
-        for (int c0 = 0; c0 < W; c0 += NT, buf ^= 1) {
-            const int c = c0 + tid;
-            const int j = beg + c;
-            const bool act = j <= end;
-            int m = POA_NEG, ev1 = POA_NEG, ev2 = POA_NEG;
-            int pm = 0, p1 = 0, p2 = 0;
-            int of1 = 0, of2 = 0;
-            int ht, hts = 0;
-            if (r > 0) {
-                const uint8_t qc = (act && j >= 1) ? (uint8_t)query[j - 1] : (uint8_t)0;
-                const int s = poa_sub(P, gb, qc);
-                for (int t = 0; t < np; t++) {
-                    int bp, ep;
-                    uint64_t pv;
-                    if (first) {
-                        const uint32_t p = plist[ps + t];
-                        bp = vbeg[p]; ep = vend[p]; pv = vvoff[p];
-                    } else { bp = prev_beg; ep = prev_end; pv = prev_voff; }
-                    const int Wp = ep - bp + 1;
-                    const int32_t *Hp = (const int32_t *)(pool + pv);
-                    const uint8_t *d1p = pool + pv + 4ull * (uint64_t)Wp;
-                    const uint8_t *d2p = d1p + Wp;
-                    if (act) {
-                        const int jm = j - 1 - bp;
-                        if (j >= 1 && jm >= 0 && j - 1 <= ep) {
-                            const int cnd = Hp[jm] + s;
-                            if (cnd > m) { m = cnd; pm = t; }
-                        }
-                        const int jj = j - bp;
-                        if (jj >= 0 && j <= ep) {
-                            const int hj = Hp[jj];
-                            const int dd1 = d1p[jj], dd2 = d2p[jj];
-                            const int c1 = hj - e1 - dd1;
-                            if (c1 > ev1) { ev1 = c1; p1 = t; of1 = dd1 == o1; }
-                            const int c2 = hj - e2 - dd2;
-                            if (c2 > ev2) { ev2 = c2; p2 = t; of2 = dd2 == o2; }
-                        }
-                    }
-                }
-                ht = m;
-                if (ev1 > ht) { ht = ev1; hts = 1; }
-                if (ev2 > ht) { ht = ev2; hts = 2; }
-            } else {
-                ht = (j == 0) ? 0 : POA_NEG;
-            }
-            // ---- insertion recurrence as a max-plus prefix scan over the row
-            const int a1 = act ? ht + e1 * j : POA_IDENT;
-            const int a2 = act ? ht + e2 * j : POA_IDENT;
-            int i1 = a1, i2 = a2;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int u1 = __shfl_up(i1, d, 64), u2 = __shfl_up(i2, d, 64);
-                if (lane >= d) { i1 = u1 > i1 ? u1 : i1; i2 = u2 > i2 ? u2 : i2; }
-            }
-            sA1[buf][tid + 1] = a1;
-            sA2[buf][tid + 1] = a2;
-            if (lane == 63) { sW1[buf][wv] = i1; sW2[buf][wv] = i2; }
-            __syncthreads();
-            int x1 = __shfl_up(i1, 1, 64), x2 = __shfl_up(i2, 1, 64);
-            if (lane == 0) { x1 = POA_IDENT; x2 = POA_IDENT; }
-            int pre1 = carry1, pre2 = carry2, all1 = carry1, all2 = carry2;
-#pragma unroll
-            for (int q = 0; q < NW; q++) {
-                const int t1 = sW1[buf][q], t2 = sW2[buf][q];
-                if (q < wv) { pre1 = t1 > pre1 ? t1 : pre1; pre2 = t2 > pre2 ? t2 : pre2; }
-                all1 = t1 > all1 ? t1 : all1;
-                all2 = t2 > all2 ? t2 : all2;
-            }
-            const int P1 = pre1 > x1 ? pre1 : x1;
-            const int P2 = pre2 > x2 ? pre2 : x2;
-            const int la1 = tid == 0 ? left1 : sA1[buf][tid];
-            const int la2 = tid == 0 ? left2 : sA2[buf][tid];
-            carry1 = all1; carry2 = all2;
-            left1 = sA1[buf][NT]; left2 = sA2[buf][NT];
-            int f1 = POA_NEG, f2 = POA_NEG, fo1 = 0, fo2 = 0;
-            if (j > beg) {
-                f1 = P1 - o1 - e1 * j;
-                f2 = P2 - o2 - e2 * j;
-                fo1 = P1 == la1;
-                fo2 = P2 == la2;
-            }
-            int h = ht, hs = hts;
-            if (f1 > h) { h = f1; hs = 3; }
-            if (f2 > h) { h = f2; hs = 4; }
-            if (act) {
-                const int lo4 = hs < 3 ? hs : 3 + (hs - 3) * 3 + hts;
-                const int code = lo4 | (fo1 << 4) | (fo2 << 5) | (of1 << 6) | (of2 << 7);
-                int dd1 = h - ev1; dd1 = dd1 < o1 ? dd1 : o1;
-                int dd2 = h - ev2; dd2 = dd2 < o2 ? dd2 : o2;
-                Hrow[c] = h;
-                d1row[c] = (uint8_t)dd1;
-                d2row[c] = (uint8_t)dd2;
-                drow[c] = (uint8_t)code;
-                if (np > 1) {
-                    drow[(uint64_t)W + c] = (uint8_t)pm;
-                    drow[2ull * W + c] = (uint8_t)p1;
-                    drow[3ull * W + c] = (uint8_t)p2;
-                }
-                if (h > best) { best = h; lpos = j; rpos = j; }
-                else if (h == best) rpos = j;
-            }
-        }
-        // ---- row maximum: leftmost / rightmost column (feeds the successors' bands)
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int ob = __shfl_xor(best, d, 64), ol = __shfl_xor(lpos, d, 64), orr = __shfl_xor(rpos, d, 64);
-            if (ob > best) { best = ob; lpos = ol; rpos = orr; }
-            else if (ob == best) { lpos = ol < lpos ? ol : lpos; rpos = orr > rpos ? orr : rpos; }
-        }
-        if (lane == 0) { sRed[wv][0] = best; sRed[wv][1] = lpos; sRed[wv][2] = rpos; }
-        __syncthreads();
-        best = sRed[0][0]; lpos = sRed[0][1]; rpos = sRed[0][2];
-#pragma unroll
-        for (int q = 1; q < NW; q++) {
-            const int ob = sRed[q][0], ol = sRed[q][1], orr = sRed[q][2];
-            if (ob > best) { best = ob; lpos = ol; rpos = orr; }
-            else if (ob == best) { lpos = ol < lpos ? ol : lpos; rpos = orr > rpos ? orr : rpos; }
-        }
-        if (tid == 0) { vlmax[r] = lpos; vrmax[r] = rpos; }
-        prev_beg = beg; prev_end = end; prev_lmax = lpos; prev_rmax = rpos; prev_voff = voff;
-        __threadfence_block();
-        __syncthreads();  // the row (values + row arrays) is complete and visible to the whole workgroup
-    }
-
-    if (tid == 0) {
-        out_cells[blockIdx.x] = cells;
-        out_vcells[blockIdx.x] = vcells;
-        if (failed) {
-            out_status[blockIdx.x] = POA_ST_POOL;
-            out_score[blockIdx.x] = POA_NEG;
-            out_row[blockIdx.x] = 0;
-        } else {
-            // sink: first predecessor (list order) with the best H at column qlen
-            int bestv = INT32_MIN;
-            uint32_t brow = 0;
-            bool have = false;
-            for (uint32_t t = 0; t < pb.n_sink; t++) {
-                const uint32_t p = sink_preds[pb.sink0 + t];
-                const int bp = vbeg[p], ep = vend[p];
-                int val = POA_NEG;
-                if (qlen >= bp && qlen <= ep) val = ((const volatile int32_t *)(pool + vvoff[p]))[qlen - bp];
-                if (!have || val > bestv) { bestv = val; brow = p; have = true; }
-            }
-            out_score[blockIdx.x] = bestv;
-            out_row[blockIdx.x] = brow;
-            out_status[blockIdx.x] = (have && bestv > POA_NEG / 2) ? POA_ST_OK : POA_ST_NOALN;
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------
-// K4 (LDS form).  Same recurrences and outputs as k_poa_dp, but the row that was just filled stays in LDS,
-// indexed by ABSOLUTE query column and overwritten in place by the next row:
-//   Hs[j]  int32  H of the current "previous row" at column j
-//   Ds[j]  uint16 d1 | d2 << 8
-// so the common predecessor (the row directly above) costs two LDS reads instead of an L2 round trip, the
-// workgroup barriers only wait for LDS (s_waitcnt lgkmcnt(0); s_barrier -- direction bytes and node-end value
-// rows are fire-and-forget global stores), and a row needs ceil(W/NT) + 1 barriers.
-// In-place hazard: inside a chunk every lane reads Hs[j-1], Hs[j] before the chunk's barrier and writes Hs[j]
-// after it; the first lane of the NEXT chunk needs the old Hs of this chunk's last column, which the last lane
-// parks in `edge` before the barrier.
-// Rows whose predecessor is not the row directly above (bubble arms, multi-predecessor rows) read that
-// predecessor's 6-byte value row from HBM; such a row starts with a full __syncthreads() (vmcnt(0)) so that the
-// stores it depends on have landed.
-// The query itself is staged in LDS too and the per-row metadata is one 16-byte scalar load, so the row loop
-// issues no vector loads at all: gfx950 retires vector memory operations in order, and a load behind the
-// direction-byte stores would wait for them to reach HBM.
-// Requires 7 * (max_qlen + 1) + scratch bytes of dynamic LDS (2 workgroups per CU up to ~11 kbp reads).
+// K4.  * The row that was just filled stays in LDS, indexed by ABSOLUTE query column and overwritten in place
+//        by the next row:  Hs[j] int32 (H), Ds[j] uint16 (d1 | d2 << 8); the common predecessor (the row directly
+//        above) costs three vector LDS reads per four cells instead of an L2 round trip.
+//      * Every lane owns four adjacent, 4-aligned columns: the insertion recurrence
+//        Fk[j] = max_{j'<j} Ht[j'] - Ok - Ek (j - j')  runs serially inside the lane and only the per-lane
+//        aggregates go through the wave scan (DPP row_shr / row_bcast, no LDS permutes).
+//      * Workgroup barriers wait for LDS only (s_waitcnt lgkmcnt(0); s_barrier): direction bytes and node-end
+//        value rows are fire-and-forget dword / dwordx4 global stores; the query is staged in LDS and the node
+//        table / node bases come through the scalar cache, so the row loop issues no vector loads at all
+//        (gfx950 retires vector memory operations in order: a load behind those stores would wait for them to
+//        reach HBM).
+//      * In-place hazard: inside a step every lane reads Hs[j0-1 .. j0+3] before the step's barrier and writes
+//        after it; the first lane of the NEXT step needs the old Hs of this step's last column, which the last
+//        lane parks in `edge` before the barrier.
+//      * Rows with a predecessor that is not the row directly above (bubble arms, multi-predecessor rows) read
+//        that predecessor's value row from HBM; such a row starts with a full __syncthreads() (vmcnt(0)).
 #define POA_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <int NT>
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int poa_dpp(int old, int v)
+{
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
+}
+// wave64 inclusive max-scan (the sequence LLVM's atomic optimizer emits for gfx9)
+__device__ __forceinline__ int poa_wave_scan_max(int v)
+{
+    int t;
+    t = poa_dpp<0x111, 0xf>(POA_IDENT, v); v = t > v ? t : v;  // row_shr:1
+    t = poa_dpp<0x112, 0xf>(POA_IDENT, v); v = t > v ? t : v;  // row_shr:2
+    t = poa_dpp<0x114, 0xf>(POA_IDENT, v); v = t > v ? t : v;  // row_shr:4
+    t = poa_dpp<0x118, 0xf>(POA_IDENT, v); v = t > v ? t : v;  // row_shr:8
+    t = poa_dpp<0x142, 0xa>(POA_IDENT, v); v = t > v ? t : v;  // row_bcast:15 -> rows 1,3
+    t = poa_dpp<0x143, 0xc>(POA_IDENT, v); v = t > v ? t : v;  // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ int poa_wave_shr1(int v) { return poa_dpp<0x138, 0xf>(POA_IDENT, v); }  // wave_shr:1
+
+template <int NT, int CPT>
 __global__ __launch_bounds__(NT) void k_poa_dp_lds(
-    const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ row_meta,
-    const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds, poa_dev_params P,
-    int32_t *row_beg, int32_t *row_end, uint64_t *row_doff, uint64_t *row_voff, int32_t *row_lmax, int32_t *row_rmax,
+    const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
+    const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
+    poa_dev_params P, int32_t *row_beg, int32_t *row_end, uint64_t *row_doff, uint64_t *row_voff, int32_t *row_lmax,
+    int32_t *row_rmax, uint2 *row_info,
     uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size, int32_t *__restrict__ out_score,
     uint32_t *__restrict__ out_row, int32_t *__restrict__ out_status, uint64_t *__restrict__ out_cells,
     uint64_t *__restrict__ out_vcells, uint32_t lds_cols)
 {
+    static_assert(CPT == 4, "row storage is 4-column aligned");
     constexpr int NW = NT / 64;
+    constexpr int STEP = NT * CPT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    int32_t *Hs = (int32_t *)smem;
-    uint16_t *Ds = (uint16_t *)(smem + 4ull * lds_cols);
-    uint8_t *Qs = smem + 6ull * lds_cols;  // the query, staged once: no vector loads in the row loop
-    int32_t *scr = (int32_t *)(smem + ((7ull * lds_cols + 15ull) & ~15ull));
+    int32_t *Hs = (int32_t *)smem;                           // [lds_cols]
+    uint16_t *Ds = (uint16_t *)(smem + 4ull * lds_cols);     // [lds_cols]
+    uint8_t *Qs = smem + 6ull * lds_cols;                    // [lds_cols] the query
+    int32_t *scr = (int32_t *)(smem + 7ull * lds_cols);      // lds_cols is a multiple of 16
     int32_t *sW1 = scr;               // [2][NW] inclusive wave maxima of a1
     int32_t *sW2 = sW1 + 2 * NW;      // [2][NW]
-    int32_t *sL1 = sW2 + 2 * NW;      // [2][NW] a1 of each wave's last lane
+    int32_t *sL1 = sW2 + 2 * NW;      // [2][NW] a1 of each wave's last cell
     int32_t *sL2 = sL1 + 2 * NW;      // [2][NW]
     int32_t *sRed = sL2 + 2 * NW;     // [NW][3]
     int32_t *edgeH = sRed + 3 * NW;   // [2]
-    int32_t *edgeD = edgeH + 2;       // [2]
-    unsigned long long *s_alloc = (unsigned long long *)(edgeD + 2);
+    unsigned long long *s_alloc = (unsigned long long *)(edgeH + 2);
 
     const poa_prob pb = probs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int qlen = (int)pb.qlen;
     const char *query = queries + pb.q0;
-    const uint4 *rmeta = row_meta + pb.row0;  // {base | flags << 8 | npred << 16, remain, pred_start, -}: one scalar load per row
+    const uint4 *ntab = node_tab + pb.node0;  // {first_row, len | npred << 24, remain_last, pred_start}: one scalar load per node
     const uint32_t *plist = preds + pb.pred0;
     volatile int32_t *vbeg = row_beg + pb.row0;
     volatile int32_t *vend = row_end + pb.row0;
@@ -384,6 +143,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
     volatile int32_t *vlmax = row_lmax + pb.row0;
     volatile int32_t *vrmax = row_rmax + pb.row0;
     uint64_t *gdoff = row_doff + pb.row0;
+    uint2 *ginfo = row_info + pb.row0;
 
     const int o1 = P.o1, e1 = P.e1, o2 = P.o2, e2 = P.e2;
     const int bw = (int)pb.w;
@@ -413,18 +173,28 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
     int prev_beg = 0, prev_end = -1, prev_lmax = 0, prev_rmax = 0;
     uint64_t cells = 0, vcells = 0;
 
-    for (uint32_t r = 0; r <= pb.N && !failed; r++) {
-        const uint4 mt = rmeta[r];
-        const uint32_t flags = (mt.x >> 8) & 255u;
-        const bool first = (flags & POA_FLAG_FIRST) != 0;
-        const bool last = (flags & POA_FLAG_LAST) != 0;
-        const int np = r == 0 ? 0 : (first ? (int)((mt.x >> 16) & 255u) : 1);
-        const uint32_t ps = mt.z;
-        // does any predecessor live in HBM (i.e. is not the row directly above)?
+    // Rows are generated from the node table: node 0 is the virtual source (one row, no predecessor), node v
+    // (v >= 1) contributes len rows whose first has the node's predecessor list and whose others follow the row
+    // above.  Everything here is wave-uniform and comes through the scalar cache.
+    for (uint32_t v = 0; v < pb.n_nodes && !failed; v++) {
+    const uint4 nt = ntab[v];
+    const uint32_t nlen = nt.y & 0xFFFFFFu;
+    for (uint32_t tn = 0; tn < nlen && !failed; tn++) {
+        const uint32_t r = nt.x + tn;
+        const bool first = tn == 0 && v > 0;
+        const bool last = tn + 1 == nlen;
+        const int np = v == 0 ? 0 : (tn == 0 ? (int)(nt.y >> 24) : 1);
+        const uint32_t ps = nt.w;
+        const int remain = (int)nt.z + (int)(nlen - 1 - tn);
+        uint8_t gb = 0;
+        if (v > 0) {
+            const uint64_t sb = pb.seq0 + (uint64_t)(r - 1);  // row r is base r-1 of the problem's node sequences
+            gb = (uint8_t)(seq32[sb >> 2] >> (8u * (uint32_t)(sb & 3u)));
+        }
         bool far = false;
         if (first)
             for (int t = 0; t < np; t++) far |= plist[ps + t] != r - 1;
-        if (far) __syncthreads();  // vmcnt(0) + barrier: value rows / row arrays of far predecessors have landed
+        if (far) __syncthreads();  // vmcnt(0) + barrier: the value rows / row arrays of far predecessors have landed
         int mpl, mpr;
         if (r == 0) { mpl = 0; mpr = 0; }
         else if (!first) { mpl = prev_lmax + 1; mpr = prev_rmax + 1; }
@@ -442,15 +212,16 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
         int beg, end;
         if (!P.banded) { beg = 0; end = qlen; }
         else {
-            const int diag = qlen - (int)mt.y;
+            const int diag = qlen - remain;
             const int lo = mpl < diag ? mpl : diag;
             const int hi = mpr > diag ? mpr : diag;
             beg = lo - bw; if (beg < 0) beg = 0;
             end = hi + bw; if (end > qlen) end = qlen;
         }
-        const int W = end - beg + 1;
-        if (r > 0) cells += (uint64_t)W;
-        if (last) vcells += (uint64_t)W;
+        const int bal = beg & ~3;
+        const int W = (end - bal + 1 + 3) & ~3;  // storage width / plane stride
+        if (r > 0) cells += (uint64_t)(end - beg + 1);
+        if (last) vcells += (uint64_t)(end - beg + 1);
         const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u));
         if (failed) break;
         uint64_t voff = 0;
@@ -460,100 +231,117 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
             vend[r] = end;
             gdoff[r] = doff;
             vvoff[r] = voff;
+            ginfo[r] = make_uint2(ps, first ? (uint32_t)np : 0u);
         }
         int32_t *Hrow = (int32_t *)(pool + voff);
         uint8_t *d1row = pool + voff + 4ull * (uint64_t)W;
         uint8_t *d2row = d1row + W;
         uint8_t *drow = pool + doff;
-        const uint8_t gb = (uint8_t)(mt.x & 255u);
 
         int carry1 = POA_IDENT, carry2 = POA_IDENT, left1 = POA_IDENT, left2 = POA_IDENT;
         int best = INT32_MIN, lpos = beg, rpos = beg;
         int buf = 0;
-        for (int c0 = 0; c0 < W; c0 += NT, buf ^= 1) {
-            const int c = c0 + tid;
-            const int j = beg + c;
-            const bool act = j <= end;
-            int m = POA_NEG, ev1 = POA_NEG, ev2 = POA_NEG;
-            int pm = 0, p1 = 0, p2 = 0;
-            int of1 = 0, of2 = 0;
-            int ht, hts = 0;
-            if (r > 0) {
-                const uint8_t qc = (act && j >= 1) ? Qs[j - 1] : (uint8_t)0;
-                const int s = poa_sub(P, gb, qc);
+        for (int c0 = 0; c0 < W; c0 += STEP, buf ^= 1) {
+            const int c = c0 + CPT * tid;   // storage index of this lane's first cell (multiple of 4)
+            const int j0 = bal + c;         // absolute column of this lane's first cell (multiple of 4)
+            const bool lane_act = j0 <= end;  // j0 + CPT - 1 >= beg always holds (bal > beg - 4)
+            int ht[CPT], hts[CPT], ev1[CPT], ev2[CPT], pmv[CPT], p1v[CPT], p2v[CPT], ofl[CPT];
+            bool act[CPT];
+#pragma unroll
+            for (int k = 0; k < CPT; k++) {
+                const int j = j0 + k;
+                act[k] = j >= beg && j <= end;
+                ht[k] = POA_NEG; hts[k] = 0; ev1[k] = POA_NEG; ev2[k] = POA_NEG; pmv[k] = 0; p1v[k] = 0; p2v[k] = 0; ofl[k] = 0;
+            }
+            if (r == 0) {
+#pragma unroll
+                for (int k = 0; k < CPT; k++) ht[k] = (j0 + k == 0) ? 0 : POA_NEG;
+            } else if (lane_act) {
+                int sub[CPT], m[CPT];
+                {
+                    // query bases j0-1 .. j0+CPT-2 (column j consumes query[j-1])
+                    const uint32_t qw = *(const uint32_t *)(Qs + j0);  // Qs[j0..j0+3]
+                    const uint8_t qm1 = j0 >= 1 ? Qs[j0 - 1] : (uint8_t)0;
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) {
+                        const uint8_t qc = k == 0 ? qm1 : (uint8_t)(qw >> (8 * (k - 1)));
+                        sub[k] = poa_sub(P, gb, (j0 + k >= 1) ? qc : (uint8_t)0);
+                        m[k] = POA_NEG;
+                    }
+                }
                 for (int t = 0; t < np; t++) {
                     const uint32_t p = first ? plist[ps + t] : r - 1;
+                    int hj[CPT], dj[CPT], hm0;
+                    int bp, ep;
                     if (p == r - 1) {
-                        // the row directly above: LDS, absolute columns
-                        int hj = POA_NEG, dj = 0;
-                        const bool inj = act && j >= prev_beg && j <= prev_end;
-                        if (inj) { hj = Hs[j]; dj = Ds[j]; }
-                        if (tid == NT - 1) { edgeH[buf] = hj; edgeD[buf] = inj ? 1 : 0; }
-                        int hm = POA_NEG;
-                        bool inm = act && j >= 1 && j - 1 >= prev_beg && j - 1 <= prev_end;
-                        if (inm) {
-                            if (tid == 0 && c0 > 0) { hm = edgeH[buf ^ 1]; inm = edgeD[buf ^ 1] != 0; }
-                            else hm = Hs[j - 1];
-                        }
-                        if (inm) {
-                            const int cnd = hm + s;
-                            if (cnd > m) { m = cnd; pm = t; }
-                        }
-                        if (inj) {
-                            const int dd1 = dj & 255, dd2 = dj >> 8;
-                            const int c1 = hj - e1 - dd1;
-                            if (c1 > ev1) { ev1 = c1; p1 = t; of1 = dd1 == o1; }
-                            const int c2 = hj - e2 - dd2;
-                            if (c2 > ev2) { ev2 = c2; p2 = t; of2 = dd2 == o2; }
-                        }
+                        bp = prev_beg; ep = prev_end;
+                        const int4 hv = *(const int4 *)(Hs + j0);
+                        const uint2 dv = *(const uint2 *)(Ds + j0);
+                        hj[0] = hv.x; hj[1] = hv.y; hj[2] = hv.z; hj[3] = hv.w;
+                        dj[0] = dv.x & 0xffff; dj[1] = dv.x >> 16; dj[2] = dv.y & 0xffff; dj[3] = dv.y >> 16;
+                        if (tid == NT - 1) edgeH[buf] = hv.w;   // old value of this step's last column
+                        hm0 = POA_NEG;
+                        if (j0 >= 1) hm0 = (tid == 0 && c0 > 0) ? edgeH[buf ^ 1] : Hs[j0 - 1];
                     } else {
-                        const int bp = vbeg[p], ep = vend[p];
+                        bp = vbeg[p]; ep = vend[p];
                         const uint64_t pv = vvoff[p];
-                        const int Wp = ep - bp + 1;
+                        const int balp = bp & ~3;
+                        const int Wp = (ep - balp + 1 + 3) & ~3;
                         const int32_t *Hp = (const int32_t *)(pool + pv);
                         const uint8_t *d1p = pool + pv + 4ull * (uint64_t)Wp;
                         const uint8_t *d2p = d1p + Wp;
-                        if (act) {
-                            const int jm = j - 1 - bp;
-                            if (j >= 1 && jm >= 0 && j - 1 <= ep) {
-                                const int cnd = Hp[jm] + s;
-                                if (cnd > m) { m = cnd; pm = t; }
-                            }
-                            const int jj = j - bp;
-                            if (jj >= 0 && j <= ep) {
-                                const int hj = Hp[jj];
-                                const int dd1 = d1p[jj], dd2 = d2p[jj];
-                                const int c1 = hj - e1 - dd1;
-                                if (c1 > ev1) { ev1 = c1; p1 = t; of1 = dd1 == o1; }
-                                const int c2 = hj - e2 - dd2;
-                                if (c2 > ev2) { ev2 = c2; p2 = t; of2 = dd2 == o2; }
-                            }
+#pragma unroll
+                        for (int k = 0; k < CPT; k++) {
+                            const int j = j0 + k;
+                            hj[k] = POA_NEG; dj[k] = 0;
+                            if (j >= bp && j <= ep) { hj[k] = Hp[j - balp]; dj[k] = (int)d1p[j - balp] | ((int)d2p[j - balp] << 8); }
+                        }
+                        hm0 = POA_NEG;
+                        if (j0 - 1 >= bp && j0 - 1 <= ep) hm0 = Hp[j0 - 1 - balp];
+                    }
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) {
+                        const int j = j0 + k;
+                        const int hm = k == 0 ? hm0 : hj[k - 1];
+                        if (act[k] && j >= 1 && j - 1 >= bp && j - 1 <= ep) {
+                            const int cnd = hm + sub[k];
+                            if (cnd > m[k]) { m[k] = cnd; pmv[k] = t; }
+                        }
+                        if (act[k] && j >= bp && j <= ep) {
+                            const int dd1 = dj[k] & 255, dd2 = dj[k] >> 8;
+                            const int c1 = hj[k] - e1 - dd1;
+                            if (c1 > ev1[k]) { ev1[k] = c1; p1v[k] = t; ofl[k] = (ofl[k] & 2) | (dd1 == o1 ? 1 : 0); }
+                            const int c2 = hj[k] - e2 - dd2;
+                            if (c2 > ev2[k]) { ev2[k] = c2; p2v[k] = t; ofl[k] = (ofl[k] & 1) | (dd2 == o2 ? 2 : 0); }
                         }
                     }
                 }
-                ht = m;
-                if (ev1 > ht) { ht = ev1; hts = 1; }
-                if (ev2 > ht) { ht = ev2; hts = 2; }
-            } else {
-                ht = (j == 0) ? 0 : POA_NEG;
-            }
-            const int a1 = act ? ht + e1 * j : POA_IDENT;
-            const int a2 = act ? ht + e2 * j : POA_IDENT;
-            int i1 = a1, i2 = a2;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int u1 = __shfl_up(i1, d, 64), u2 = __shfl_up(i2, d, 64);
-                if (lane >= d) { i1 = u1 > i1 ? u1 : i1; i2 = u2 > i2 ? u2 : i2; }
+                for (int k = 0; k < CPT; k++) {
+                    ht[k] = m[k];
+                    if (ev1[k] > ht[k]) { ht[k] = ev1[k]; hts[k] = 1; }
+                    if (ev2[k] > ht[k]) { ht[k] = ev2[k]; hts[k] = 2; }
+                }
             }
+            // ---- insertion recurrence: serial inside the lane, scan of the lane aggregates across the wave
+            int a1[CPT], a2[CPT];
+            int agg1 = POA_IDENT, agg2 = POA_IDENT;
+#pragma unroll
+            for (int k = 0; k < CPT; k++) {
+                a1[k] = act[k] ? ht[k] + e1 * (j0 + k) : POA_IDENT;
+                a2[k] = act[k] ? ht[k] + e2 * (j0 + k) : POA_IDENT;
+                agg1 = a1[k] > agg1 ? a1[k] : agg1;
+                agg2 = a2[k] > agg2 ? a2[k] : agg2;
+            }
+            const int i1 = poa_wave_scan_max(agg1), i2 = poa_wave_scan_max(agg2);
             if (lane == 63) {
                 sW1[buf * NW + wv] = i1; sW2[buf * NW + wv] = i2;
-                sL1[buf * NW + wv] = a1; sL2[buf * NW + wv] = a2;
+                sL1[buf * NW + wv] = a1[CPT - 1]; sL2[buf * NW + wv] = a2[CPT - 1];
             }
             POA_LDS_BARRIER();
-            int x1 = __shfl_up(i1, 1, 64), x2 = __shfl_up(i2, 1, 64);
-            int la1 = __shfl_up(a1, 1, 64), la2 = __shfl_up(a2, 1, 64);
+            int x1 = poa_wave_shr1(i1), x2 = poa_wave_shr1(i2);
+            int la1 = poa_wave_shr1(a1[CPT - 1]), la2 = poa_wave_shr1(a2[CPT - 1]);
             if (lane == 0) {
-                x1 = POA_IDENT; x2 = POA_IDENT;
                 la1 = wv == 0 ? left1 : sL1[buf * NW + wv - 1];
                 la2 = wv == 0 ? left2 : sL2[buf * NW + wv - 1];
             }
@@ -565,40 +353,52 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
                 all1 = t1 > all1 ? t1 : all1;
                 all2 = t2 > all2 ? t2 : all2;
             }
-            const int P1 = pre1 > x1 ? pre1 : x1;
-            const int P2 = pre2 > x2 ? pre2 : x2;
+            int run1 = pre1 > x1 ? pre1 : x1;   // max of a1 over every column before this lane's first cell
+            int run2 = pre2 > x2 ? pre2 : x2;
             carry1 = all1; carry2 = all2;
             left1 = sL1[buf * NW + NW - 1]; left2 = sL2[buf * NW + NW - 1];
-            int f1 = POA_NEG, f2 = POA_NEG, fo1 = 0, fo2 = 0;
-            if (j > beg) {
-                f1 = P1 - o1 - e1 * j;
-                f2 = P2 - o2 - e2 * j;
-                fo1 = P1 == la1;
-                fo2 = P2 == la2;
-            }
-            int h = ht, hs = hts;
-            if (f1 > h) { h = f1; hs = 3; }
-            if (f2 > h) { h = f2; hs = 4; }
-            if (act) {
-                const int lo4 = hs < 3 ? hs : 3 + (hs - 3) * 3 + hts;
-                const int code = lo4 | (fo1 << 4) | (fo2 << 5) | (of1 << 6) | (of2 << 7);
-                int dd1 = h - ev1; dd1 = dd1 < o1 ? dd1 : o1;
-                int dd2 = h - ev2; dd2 = dd2 < o2 ? dd2 : o2;
-                Hs[j] = h;
-                Ds[j] = (uint16_t)(dd1 | (dd2 << 8));
-                drow[c] = (uint8_t)code;
+            if (lane_act) {
+                int hv[CPT], codev[CPT], d1v[CPT], d2v[CPT];
+#pragma unroll
+                for (int k = 0; k < CPT; k++) {
+                    const int j = j0 + k;
+                    int f1 = POA_NEG, f2 = POA_NEG, fo1 = 0, fo2 = 0;
+                    if (j > beg) {
+                        f1 = run1 - o1 - e1 * j;
+                        f2 = run2 - o2 - e2 * j;
+                        fo1 = run1 == la1;
+                        fo2 = run2 == la2;
+                    }
+                    int h = ht[k], hs = hts[k];
+                    if (f1 > h) { h = f1; hs = 3; }
+                    if (f2 > h) { h = f2; hs = 4; }
+                    const int lo4 = hs < 3 ? hs : 3 + (hs - 3) * 3 + hts[k];
+                    codev[k] = lo4 | (fo1 << 4) | (fo2 << 5) | ((ofl[k] & 1) << 6) | ((ofl[k] & 2) << 6);
+                    int dd1 = h - ev1[k]; dd1 = dd1 < o1 ? dd1 : o1;
+                    int dd2 = h - ev2[k]; dd2 = dd2 < o2 ? dd2 : o2;
+                    hv[k] = h; d1v[k] = dd1; d2v[k] = dd2;
+                    if (act[k]) {
+                        if (h > best) { best = h; lpos = j; rpos = j; }
+                        else if (h == best) rpos = j;
+                        run1 = a1[k] > run1 ? a1[k] : run1;
+                        run2 = a2[k] > run2 ? a2[k] : run2;
+                        la1 = a1[k]; la2 = a2[k];
+                    }
+                }
+                *(int4 *)(Hs + j0) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+                *(uint2 *)(Ds + j0) = make_uint2((uint32_t)(d1v[0] | (d2v[0] << 8)) | ((uint32_t)(d1v[1] | (d2v[1] << 8)) << 16),
+                                                  (uint32_t)(d1v[2] | (d2v[2] << 8)) | ((uint32_t)(d1v[3] | (d2v[3] << 8)) << 16));
+                *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
                 if (last) {
-                    Hrow[c] = h;
-                    d1row[c] = (uint8_t)dd1;
-                    d2row[c] = (uint8_t)dd2;
+                    *(int4 *)(Hrow + c) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+                    *(uint32_t *)(d1row + c) = (uint32_t)d1v[0] | ((uint32_t)d1v[1] << 8) | ((uint32_t)d1v[2] << 16) | ((uint32_t)d1v[3] << 24);
+                    *(uint32_t *)(d2row + c) = (uint32_t)d2v[0] | ((uint32_t)d2v[1] << 8) | ((uint32_t)d2v[2] << 16) | ((uint32_t)d2v[3] << 24);
                 }
                 if (np > 1) {
-                    drow[(uint64_t)W + c] = (uint8_t)pm;
-                    drow[2ull * W + c] = (uint8_t)p1;
-                    drow[3ull * W + c] = (uint8_t)p2;
+                    *(uint32_t *)(drow + (uint64_t)W + c) = (uint32_t)pmv[0] | ((uint32_t)pmv[1] << 8) | ((uint32_t)pmv[2] << 16) | ((uint32_t)pmv[3] << 24);
+                    *(uint32_t *)(drow + 2ull * W + c) = (uint32_t)p1v[0] | ((uint32_t)p1v[1] << 8) | ((uint32_t)p1v[2] << 16) | ((uint32_t)p1v[3] << 24);
+                    *(uint32_t *)(drow + 3ull * W + c) = (uint32_t)p2v[0] | ((uint32_t)p2v[1] << 8) | ((uint32_t)p2v[2] << 16) | ((uint32_t)p2v[3] << 24);
                 }
-                if (h > best) { best = h; lpos = j; rpos = j; }
-                else if (h == best) rpos = j;
             }
         }
 #pragma unroll
@@ -619,6 +419,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
         if (tid == 0) { vlmax[r] = lpos; vrmax[r] = rpos; }
         prev_beg = beg; prev_end = end; prev_lmax = lpos; prev_rmax = rpos;
     }
+    }
     __syncthreads();
     if (tid == 0) {
         out_cells[blockIdx.x] = cells;
@@ -635,7 +436,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
                 const uint32_t p = sink_preds[pb.sink0 + t];
                 const int bp = vbeg[p], ep = vend[p];
                 int val = POA_NEG;
-                if (qlen >= bp && qlen <= ep) val = ((const volatile int32_t *)(pool + vvoff[p]))[qlen - bp];
+                if (qlen >= bp && qlen <= ep) val = ((const volatile int32_t *)(pool + vvoff[p]))[qlen - (bp & ~3)];
                 if (!have || val > bestv) { bestv = val; brow = p; have = true; }
             }
             out_score[blockIdx.x] = bestv;
@@ -645,15 +446,9 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
     }
 }
 
-static inline size_t poa_lds_bytes(uint32_t lds_cols, int nt)
-{
-    const int nw = nt / 64;
-    return ((7ull * lds_cols + 15ull) & ~15ull) + (size_t)(8 * nw + 3 * nw + 4) * 4 + 16;
-}
-
 // K4b: one lane per problem.  ops are written in reverse (sink -> source) order.
 __global__ __launch_bounds__(64) void k_poa_traceback(
-    uint32_t n, const poa_prob *__restrict__ probs, const uint4 *__restrict__ row_meta,
+    uint32_t n, const poa_prob *__restrict__ probs, const uint2 *__restrict__ row_info,
     const uint32_t *__restrict__ preds, const int32_t *__restrict__ row_beg, const int32_t *__restrict__ row_end,
     const uint64_t *__restrict__ row_doff, const uint8_t *__restrict__ pool, const uint32_t *__restrict__ out_row,
     int32_t *__restrict__ out_status, uint8_t *__restrict__ ops, uint32_t *__restrict__ orow,
@@ -674,15 +469,15 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
     bool bad = false;
     while (i > 0 && !bad) {
         const uint64_t ri = pb.row0 + i;
-        const uint4 mt = row_meta[ri];
-        const uint32_t flags = (mt.x >> 8) & 255u;
-        const bool first = (flags & POA_FLAG_FIRST) != 0;
-        const int np = first ? (int)((mt.x >> 16) & 255u) : 1;
+        const uint2 inf = row_info[ri];  // {pred_start, npred if this row starts a node else 0}
+        const bool first = inf.y != 0;
+        const int np = first ? (int)inf.y : 1;
         const int beg = row_beg[ri], end = row_end[ri];
-        const uint64_t W = (uint64_t)(end - beg + 1);
+        const int bal = beg & ~3;
+        const uint64_t W = (uint64_t)((end - bal + 1 + 3) & ~3);
         const uint64_t doff = row_doff[ri];
         if (j < beg || j > end) { bad = true; break; }
-        const uint64_t c = (uint64_t)(j - beg);
+        const uint64_t c = (uint64_t)(j - bal);
         const int code = pool[doff + c];
         const int lo4 = code & 15;
         const int hs = lo4 < 3 ? lo4 : 3 + (lo4 - 3) / 3;
@@ -691,13 +486,13 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
         if (nops + 1 >= cap) { bad = true; break; }
         if (src == 0) {
             const int t = np > 1 ? pool[doff + W + c] : 0;
-            const uint32_t p = first ? preds[pb.pred0 + mt.z + t] : i - 1;
+            const uint32_t p = first ? preds[pb.pred0 + inf.x + t] : i - 1;
             if (j < 1) { bad = true; break; }
             po[nops] = 0; pr[nops] = i; nops++;
             i = p; j -= 1; st = 0;
         } else if (src == 1 || src == 2) {
             const int t = np > 1 ? pool[doff + (src == 1 ? 2 : 3) * W + c] : 0;
-            const uint32_t p = first ? preds[pb.pred0 + mt.z + t] : i - 1;
+            const uint32_t p = first ? preds[pb.pred0 + inf.x + t] : i - 1;
             const int open = (code >> (src == 1 ? 6 : 7)) & 1;
             po[nops] = 2; pr[nops] = i; nops++;
             st = open ? 0 : src;
@@ -719,100 +514,111 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
     out_nops[pi] = (uint32_t)nops;
 }
 
+static inline uint32_t poa_lds_cols(uint32_t max_q) { return ((max_q + 1 + 15u) & ~15u) + 16u; }
+
+static inline size_t poa_lds_bytes(uint32_t lds_cols, int nt)
+{
+    const int nw = nt / 64;
+    return 7ull * lds_cols + (size_t)(8 * nw + 3 * nw + 2) * 4 + 16;
+}
+
 // ============================================================================================ host
 namespace {
 
-struct poa_graph_host {
+struct poa_prep {
+    bool ok = false;
     uint32_t N = 0, qlen = 0;
-    std::vector<uint8_t> base, flags, npred;
-    std::vector<int32_t> remain;
-    std::vector<uint32_t> pred_start, preds, sink, row_node, first_row;
+    int32_t longest = 0;                // graph bases on the longest source-sink path
+    std::vector<uint4> ntab;            // node table incl. the source entry
+    std::vector<uint32_t> preds, sinks; // row ids
+    std::vector<uint32_t> first_row;    // per input node
 };
 
-// rows, predecessor lists (edge-list order), remain[]; mirrors the row construction of
-// oracle/og_poa.c (which restates abPOA's graph of single-base nodes).  Returns false on bad input.
-bool poa_prepare(const uint64_t *node_off, uint64_t n_nodes, const char *nodes_concat, const uint32_t *esrc,
-                 const uint32_t *edst, uint64_t n_edges, uint32_t qlen, poa_graph_host &g)
+// Node-level graph description: first rows, predecessor rows in edge-list order, remain of the last base of each
+// node (longest-path DP over the nodes), sink predecessors.  Mirrors the row construction of oracle/og_poa.c.
+void poa_prepare(const poa_view &v, poa_prep &g)
 {
-    if (n_nodes == 0) return false;
-    std::vector<uint32_t> last_row(n_nodes);
-    g.first_row.resize(n_nodes);
+    g.ok = false;
+    const uint64_t nv = v.n_nodes;
+    if (nv == 0 || v.qlen >= (1u << 24)) return;
+    g.first_row.resize(nv);
+    std::vector<uint32_t> last_row(nv);
     uint64_t N = 0;
-    for (uint64_t v = 0; v < n_nodes; v++) {
-        uint64_t len = node_off[v + 1] - node_off[v];
-        if (len == 0) return false;
-        g.first_row[v] = (uint32_t)(N + 1);
+    for (uint64_t i = 0; i < nv; i++) {
+        const uint64_t len = v.node_off[i + 1] - v.node_off[i];
+        if (len == 0 || len >= (1u << 24)) return;
+        g.first_row[i] = (uint32_t)(N + 1);
         N += len;
-        last_row[v] = (uint32_t)N;
+        last_row[i] = (uint32_t)N;
     }
-    if (N >= (1ull << 31)) return false;
+    if (N >= (1ull << 31)) return;
     g.N = (uint32_t)N;
-    g.qlen = qlen;
-    g.base.assign(N + 1, 0);
-    g.flags.assign(N + 1, 0);
-    g.npred.assign(N + 1, 1);
-    g.remain.assign(N + 1, 0);
-    g.pred_start.assign(N + 1, 0);
-    g.row_node.assign(N + 1, 0);
-    std::vector<uint32_t> in_off(n_nodes + 1, 0), out_off(n_nodes + 1, 0);
-    for (uint64_t e = 0; e < n_edges; e++) {
-        if (esrc[e] >= edst[e] || edst[e] >= n_nodes) return false;
-        in_off[edst[e] + 1]++;
-        out_off[esrc[e] + 1]++;
+    g.qlen = v.qlen;
+    std::vector<uint32_t> in_off(nv + 1, 0), out_off(nv + 1, 0);
+    for (uint64_t e = 0; e < v.n_edges; e++) {
+        if (v.esrc[e] >= v.edst[e] || v.edst[e] >= nv) return;
+        in_off[v.edst[e] + 1]++;
+        out_off[v.esrc[e] + 1]++;
     }
-    for (uint64_t v = 0; v < n_nodes; v++) { in_off[v + 1] += in_off[v]; out_off[v + 1] += out_off[v]; }
-    std::vector<uint32_t> in_adj(n_edges ? n_edges : 1), out_adj(n_edges ? n_edges : 1), fi(n_nodes, 0), fo(n_nodes, 0);
-    for (uint64_t e = 0; e < n_edges; e++) {
-        in_adj[in_off[edst[e]] + fi[edst[e]]++] = esrc[e];
-        out_adj[out_off[esrc[e]] + fo[esrc[e]]++] = edst[e];
+    for (uint64_t i = 0; i < nv; i++) { in_off[i + 1] += in_off[i]; out_off[i + 1] += out_off[i]; }
+    std::vector<uint32_t> in_adj(v.n_edges ? v.n_edges : 1), out_adj(v.n_edges ? v.n_edges : 1), fi(nv, 0), fo(nv, 0);
+    for (uint64_t e = 0; e < v.n_edges; e++) {
+        in_adj[in_off[v.edst[e]] + fi[v.edst[e]]++] = v.esrc[e];
+        out_adj[out_off[v.esrc[e]] + fo[v.esrc[e]]++] = v.edst[e];
     }
-    g.flags[0] = POA_FLAG_LAST;
-    g.npred[0] = 0;
-    g.preds.clear();
-    for (uint64_t v = 0; v < n_nodes; v++) {
-        const char *s = nodes_concat + node_off[v];
-        uint32_t fr = g.first_row[v], lr = last_row[v];
-        for (uint32_t r = fr; r <= lr; r++) { g.base[r] = (uint8_t)s[r - fr]; g.row_node[r] = (uint32_t)v; }
-        g.flags[fr] |= POA_FLAG_FIRST;
-        g.flags[lr] |= POA_FLAG_LAST;
-        g.pred_start[fr] = (uint32_t)g.preds.size();
-        uint32_t deg = in_off[v + 1] - in_off[v];
-        if (deg == 0) { g.preds.push_back(0); g.npred[fr] = 1; }
-        else {
-            if (deg > 255) return false;
-            for (uint32_t t = in_off[v]; t < in_off[v + 1]; t++) g.preds.push_back(last_row[in_adj[t]]);
-            g.npred[fr] = (uint8_t)deg;
-        }
-        if (out_off[v + 1] == out_off[v]) g.sink.push_back(lr);
-    }
-    for (uint64_t v = n_nodes; v-- > 0;) {
+    // remain of the LAST base of each node; interior bases add their distance to it on the device
+    std::vector<int32_t> remain_last(nv, 0), remain_first(nv, 0);
+    for (uint64_t i = nv; i-- > 0;) {
         int32_t rl = 0;
-        for (uint32_t t = out_off[v]; t < out_off[v + 1]; t++) {
-            int32_t c = 1 + g.remain[g.first_row[out_adj[t]]];
-            if (c > rl) rl = c;
-        }
-        g.remain[last_row[v]] = rl;
-        for (uint32_t r = last_row[v]; r-- > g.first_row[v];) g.remain[r] = g.remain[r + 1] + 1;
+        for (uint32_t t = out_off[i]; t < out_off[i + 1]; t++) rl = std::max(rl, 1 + remain_first[out_adj[t]]);
+        remain_last[i] = rl;
+        remain_first[i] = rl + (int32_t)(last_row[i] - g.first_row[i]);
     }
-    for (uint64_t v = 0; v < n_nodes; v++)
-        if (in_off[v + 1] == in_off[v]) {
-            int32_t c = 1 + g.remain[g.first_row[v]];
-            if (c > g.remain[0]) g.remain[0] = c;
+    int32_t longest = 0;
+    g.ntab.clear();
+    g.preds.clear();
+    g.sinks.clear();
+    g.ntab.resize(nv + 1);
+    for (uint64_t i = 0; i < nv; i++) {
+        const uint32_t deg = in_off[i + 1] - in_off[i];
+        if (deg > 255) return;
+        const uint32_t pstart = (uint32_t)g.preds.size();
+        if (deg == 0) {
+            g.preds.push_back(0);
+            longest = std::max(longest, 1 + remain_first[i]);
+        } else {
+            for (uint32_t t = in_off[i]; t < in_off[i + 1]; t++) g.preds.push_back(last_row[in_adj[t]]);
         }
-    return true;
+        const uint32_t len = last_row[i] - g.first_row[i] + 1;
+        g.ntab[i + 1] = make_uint4(g.first_row[i], len | ((deg ? deg : 1u) << 24), (uint32_t)remain_last[i], pstart);
+        if (out_off[i + 1] == out_off[i]) g.sinks.push_back(last_row[i]);
+    }
+    g.longest = longest;
+    g.ntab[0] = make_uint4(0u, 1u, (uint32_t)longest, 0u);  // the virtual source: row 0, remain = longest path
+    g.ok = true;
 }
 
 struct poa_ws {
     vga_dbuf<poa_prob> d_probs;
-    vga_dbuf<uint4> d_meta;
+    vga_dbuf<uint4> d_ntab;
+    vga_dbuf<uint32_t> d_seq32, d_preds, d_sink, d_row, d_orow, d_nops;
     vga_dbuf<uint8_t> d_ops;
     vga_dbuf<int32_t> d_beg, d_end, d_lmax, d_rmax, d_score, d_status;
-    vga_dbuf<uint32_t> d_preds, d_sink, d_row, d_orow, d_nops;
     vga_dbuf<uint64_t> d_doff, d_voff, d_cells, d_vcells;
+    vga_dbuf<uint2> d_info;
     vga_dbuf<char> d_q;
     vga_dbuf<unsigned long long> d_next;
+    vga_hbuf<poa_prob> h_probs;
+    vga_hbuf<uint4> h_ntab;
+    vga_hbuf<uint32_t> h_seq32, h_preds, h_sink, h_orow, h_row, h_nops;
+    vga_hbuf<uint8_t> h_ops;
+    vga_hbuf<int32_t> h_score, h_status;
+    vga_hbuf<uint64_t> h_cells, h_vcells;
+    vga_hbuf<char> h_q;
+    vga_hbuf<unsigned long long> h_next;
     uint8_t *pool = nullptr;
     uint64_t pool_size = 0;
+    double pool_scale = 0.30;  // measured pool bytes / estimated bytes, adapted after every sub-batch
     ~poa_ws() { if (pool) (void)hipFree(pool); }
 };
 
@@ -831,7 +637,333 @@ void append_u(std::string &s, uint64_t v)
 
 inline char lower(char c) { return (c >= 'A' && c <= 'Z') ? (char)(c + 32) : c; }
 
+unsigned host_threads(uint64_t n)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 32) nt = 32;
+    if ((uint64_t)nt > n) nt = (unsigned)std::max<uint64_t>(n, 1);
+    return nt;
+}
+
+template <typename F>
+void parallel_for(uint64_t n, F f)
+{
+    unsigned nt = host_threads(n);
+    if (nt <= 1) { for (uint64_t i = 0; i < n; i++) f(i); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t]() { for (uint64_t i = t; i < n; i += nt) f(i); });
+    for (auto &x : th) x.join();
+}
+
 }  // namespace
+
+int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_params *params, std::vector<poa_item> &out,
+            poa_timing &tm)
+{
+    const uint64_t n = views.size();
+    out.assign(n, poa_item());
+    tm = poa_timing();
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    auto t_host0 = std::chrono::steady_clock::now();
+    vga_trace tr("poa");
+    if (params->gap_open1 < 0 || params->gap_open1 > 255 || params->gap_open2 < 0 || params->gap_open2 > 255 ||
+        params->gap_ext1 < 0 || params->gap_ext2 < 0)
+        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "gap open penalties must be in 0..255");
+    vga_timers_reset(ctx);
+    if (n == 0) return VGA_OK;
+
+    // ---- host: node-level graph descriptions (threads over problems)
+    std::vector<poa_prep> G(n);
+    parallel_for(n, [&](uint64_t p) { poa_prepare(views[p], G[p]); });
+    for (uint64_t p = 0; p < n; p++)
+        if (!G[p].ok)
+            return vga_set_error(ctx, VGA_ERR_ARG,
+                                 "POA problem %llu is malformed (no node, empty node, edge with src >= dst, in-degree > 255, "
+                                 "or sequence too long)", (unsigned long long)p);
+    uint32_t max_q = 0;
+    for (uint64_t p = 0; p < n; p++) max_q = std::max(max_q, G[p].qlen);
+    const uint32_t lds_cols_all = poa_lds_cols(max_q);
+    if (poa_lds_bytes(lds_cols_all, 128) > 160 * 1024 - 256)
+        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query of %u bases: the LDS-resident POA kernel handles up to ~22 kbp", max_q);
+    tr.mark("node tables (host threads)");
+
+    // ---- flatten into pinned staging (offsets first, then a parallel fill)
+    std::vector<poa_prob> probs(n);
+    uint64_t tot_nodes = 0, tot_preds = 0, tot_sink = 0, tot_q = 0, tot_ops = 0, tot_rows = 0, tot_seq = 0;
+    for (uint64_t p = 0; p < n; p++) {
+        poa_prob &pb = probs[p];
+        const poa_prep &g = G[p];
+        pb.node0 = tot_nodes; pb.pred0 = tot_preds; pb.sink0 = tot_sink; pb.q0 = tot_q; pb.ops0 = tot_ops; pb.row0 = tot_rows;
+        pb.seq0 = tot_seq;
+        pb.n_sink = (uint32_t)g.sinks.size(); pb.qlen = g.qlen; pb.N = g.N; pb.n_nodes = (uint32_t)g.ntab.size(); pb.pad = 0;
+        pb.w = params->wb < 0 ? g.qlen : (uint32_t)((int64_t)params->wb + (int64_t)(params->wf * (double)g.qlen));
+        tot_nodes += g.ntab.size();
+        tot_preds += g.preds.size();
+        tot_sink += g.sinks.size();
+        tot_q += g.qlen;
+        tot_ops += (uint64_t)g.N + g.qlen + 2;
+        tot_rows += (uint64_t)g.N + 1;
+        tot_seq += ((uint64_t)g.N + 3) & ~3ull;
+        out[p].n_rows = g.N;
+    }
+    if (!ctx->poa_ws) {
+        ctx->poa_ws = new poa_ws();
+        ctx->poa_ws_free = [](void *q) { delete (poa_ws *)q; };
+    }
+    poa_ws &W = *(poa_ws *)ctx->poa_ws;
+#define POA_CHECK(call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return vga_set_error(ctx, VGA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                                 __LINE__);                                                          \
+    } while (0)
+    POA_CHECK(W.h_probs.reserve(n)); POA_CHECK(W.h_ntab.reserve(tot_nodes)); POA_CHECK(W.h_seq32.reserve(tot_seq / 4 + 1));
+    POA_CHECK(W.h_preds.reserve(tot_preds + 1)); POA_CHECK(W.h_sink.reserve(tot_sink + 1)); POA_CHECK(W.h_q.reserve(tot_q + 1));
+    POA_CHECK(W.h_ops.reserve(tot_ops)); POA_CHECK(W.h_orow.reserve(tot_ops)); POA_CHECK(W.h_row.reserve(n));
+    POA_CHECK(W.h_nops.reserve(n)); POA_CHECK(W.h_score.reserve(n)); POA_CHECK(W.h_status.reserve(n));
+    POA_CHECK(W.h_cells.reserve(n)); POA_CHECK(W.h_vcells.reserve(n)); POA_CHECK(W.h_next.reserve(1));
+    POA_CHECK(W.d_probs.reserve(n)); POA_CHECK(W.d_ntab.reserve(tot_nodes)); POA_CHECK(W.d_seq32.reserve(tot_seq / 4 + 1));
+    POA_CHECK(W.d_preds.reserve(tot_preds + 1)); POA_CHECK(W.d_sink.reserve(tot_sink + 1)); POA_CHECK(W.d_q.reserve(tot_q + 1));
+    POA_CHECK(W.d_beg.reserve(tot_rows)); POA_CHECK(W.d_end.reserve(tot_rows)); POA_CHECK(W.d_doff.reserve(tot_rows));
+    POA_CHECK(W.d_voff.reserve(tot_rows)); POA_CHECK(W.d_lmax.reserve(tot_rows)); POA_CHECK(W.d_rmax.reserve(tot_rows));
+    POA_CHECK(W.d_info.reserve(tot_rows));
+    POA_CHECK(W.d_score.reserve(n)); POA_CHECK(W.d_status.reserve(n)); POA_CHECK(W.d_row.reserve(n)); POA_CHECK(W.d_cells.reserve(n));
+    POA_CHECK(W.d_vcells.reserve(n)); POA_CHECK(W.d_ops.reserve(tot_ops)); POA_CHECK(W.d_orow.reserve(tot_ops));
+    POA_CHECK(W.d_nops.reserve(n)); POA_CHECK(W.d_next.reserve(1));
+    tr.mark("reserve");
+    parallel_for(n, [&](uint64_t p) {
+        const poa_prob &pb = probs[p];
+        const poa_prep &g = G[p];
+        memcpy(W.h_ntab.p + pb.node0, g.ntab.data(), g.ntab.size() * sizeof(uint4));
+        if (!g.preds.empty()) memcpy(W.h_preds.p + pb.pred0, g.preds.data(), g.preds.size() * 4);
+        if (!g.sinks.empty()) memcpy(W.h_sink.p + pb.sink0, g.sinks.data(), g.sinks.size() * 4);
+        // node strings of one problem are contiguous in the view
+        memcpy((char *)W.h_seq32.p + pb.seq0, views[p].nodes + views[p].node_off[0], g.N);
+        if (g.qlen) memcpy(W.h_q.p + pb.q0, views[p].query, g.qlen);
+    });
+    tr.mark("fill staging (host threads)");
+
+    // ---- pool sizing and the launch order (longest estimated problem first, so stragglers start early)
+    auto est_bytes = [&](uint64_t p) -> double {
+        const poa_prep &g = G[p];
+        const double w = params->wb < 0 ? (double)g.qlen : (double)params->wb + (double)(uint64_t)(params->wf * (double)g.qlen);
+        double excess = (double)g.longest - (double)g.qlen;
+        if (excess < 0) excess = -excess;
+        const double width = std::min((double)g.qlen + 1.0, 2.0 * w + 1.0 + excess + 64.0);
+        return (double)g.N * width * 2.6;
+    };
+    std::vector<double> est(n);
+    std::vector<uint32_t> order(n);
+    for (uint64_t p = 0; p < n; p++) { est[p] = est_bytes(p); order[p] = (uint32_t)p; }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return est[a] > est[b]; });
+    for (uint64_t i = 0; i < n; i++) W.h_probs.p[i] = probs[order[i]];
+    {
+        double want_d = 0;
+        for (uint64_t p = 0; p < n; p++) want_d += est[p] * W.pool_scale * 1.3 + 3.0 * (double)POA_CHUNK;
+        uint64_t want = (uint64_t)want_d + 64 * POA_CHUNK;
+        const char *env_pool = getenv("VGA_POOL_BYTES");
+        if (env_pool) want = std::min<uint64_t>(want, strtoull(env_pool, nullptr, 10));
+        if (W.pool_size < want) {
+            size_t free_b = 0, total_b = 0;
+            POA_CHECK(hipMemGetInfo(&free_b, &total_b));
+            const uint64_t avail = (uint64_t)((double)(free_b + W.pool_size) * 0.85);
+            const uint64_t target = std::min(want, avail) & ~(POA_CHUNK - 1);
+            if (target > W.pool_size) {
+                if (W.pool) { (void)hipFree(W.pool); W.pool = nullptr; W.pool_size = 0; }
+                if (target < 64 * POA_CHUNK)
+                    return vga_set_error(ctx, VGA_ERR_NOMEM, "only %llu bytes of HBM free for the traceback pool", (unsigned long long)free_b);
+                POA_CHECK(hipMalloc((void **)&W.pool, target));
+                W.pool_size = target;
+            }
+        }
+    }
+    tr.mark("pool");
+    POA_CHECK(hipMemcpyAsync(W.d_probs.p, W.h_probs.p, n * sizeof(poa_prob), hipMemcpyHostToDevice, st));
+    POA_CHECK(hipMemcpyAsync(W.d_ntab.p, W.h_ntab.p, tot_nodes * sizeof(uint4), hipMemcpyHostToDevice, st));
+    POA_CHECK(hipMemcpyAsync(W.d_seq32.p, W.h_seq32.p, tot_seq, hipMemcpyHostToDevice, st));
+    POA_CHECK(hipMemcpyAsync(W.d_preds.p, W.h_preds.p, tot_preds * 4, hipMemcpyHostToDevice, st));
+    POA_CHECK(hipMemcpyAsync(W.d_sink.p, W.h_sink.p, tot_sink * 4, hipMemcpyHostToDevice, st));
+    POA_CHECK(hipMemcpyAsync(W.d_q.p, W.h_q.p, tot_q, hipMemcpyHostToDevice, st));
+
+    poa_dev_params P;
+    P.match = params->match; P.mismatch = params->mismatch; P.o1 = params->gap_open1; P.e1 = params->gap_ext1;
+    P.o2 = params->gap_open2; P.e2 = params->gap_ext2; P.banded = params->wb >= 0;
+
+    int t_total = vga_timer_begin(ctx, "poa_total", 0);
+    uint64_t i0 = 0;
+    int rc_final = VGA_OK;
+    while (i0 < n) {
+        const double budget = (double)W.pool_size * 0.92;
+        double used_est = 0, raw_est = 0;
+        uint64_t i1 = i0;
+        while (i1 < n) {
+            const double e = est[order[i1]] * W.pool_scale + 3.0 * (double)POA_CHUNK;
+            if (i1 > i0 && used_est + e > budget) break;
+            used_est += e;
+            raw_est += est[order[i1]];
+            i1++;
+        }
+        const uint32_t nb = (uint32_t)(i1 - i0);
+        POA_CHECK(hipMemsetAsync(W.d_next.p, 0, sizeof(unsigned long long), st));
+        int t_dp = vga_timer_begin(ctx, "poa_band_dp", 0);
+        {
+            uint32_t mq = 0;
+            for (uint64_t i = i0; i < i1; i++) mq = std::max(mq, G[order[i]].qlen);
+            const uint32_t lds_cols = poa_lds_cols(mq);
+            const char *force = getenv("VGA_POA_KERNEL");  // "lds128" | "lds256" | "lds512" (testing)
+            int nt = mq >= 3072 ? 512 : (mq >= 768 ? 256 : 128);
+            if (force) {
+                if (!strcmp(force, "lds128")) nt = 128;
+                else if (!strcmp(force, "lds256")) nt = 256;
+                else if (!strcmp(force, "lds512")) nt = 512;
+            }
+            while (nt > 128 && poa_lds_bytes(lds_cols, nt) > 160 * 1024 - 256) nt /= 2;
+            const size_t lds = poa_lds_bytes(lds_cols, nt);
+#define POA_ARGS W.d_probs.p + i0, W.d_q.p, W.d_ntab.p, W.d_seq32.p, W.d_preds.p, W.d_sink.p, P, W.d_beg.p, W.d_end.p, W.d_doff.p,   \
+                 W.d_voff.p, W.d_lmax.p, W.d_rmax.p, W.d_info.p, W.pool, W.d_next.p, W.pool_size, W.d_score.p + i0, W.d_row.p + i0, \
+                 W.d_status.p + i0, W.d_cells.p + i0, W.d_vcells.p + i0, lds_cols
+            if (nt == 128) {
+                POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_poa_dp_lds<128, 4>), dim3(nb), dim3(128), lds, st, POA_ARGS);
+            } else if (nt == 256) {
+                POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_poa_dp_lds<256, 4>), dim3(nb), dim3(256), lds, st, POA_ARGS);
+            } else {
+                POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_poa_dp_lds<512, 4>), dim3(nb), dim3(512), lds, st, POA_ARGS);
+            }
+#undef POA_ARGS
+            POA_CHECK(hipGetLastError());
+        }
+        vga_timer_end(ctx, t_dp);
+        int t_tb = vga_timer_begin(ctx, "poa_traceback", 0);
+        hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, W.d_probs.p + i0, W.d_info.p, W.d_preds.p,
+                           W.d_beg.p, W.d_end.p, W.d_doff.p, W.pool, W.d_row.p + i0, W.d_status.p + i0, W.d_ops.p, W.d_orow.p,
+                           W.d_nops.p + i0);
+        vga_timer_end(ctx, t_tb);
+        POA_CHECK(hipMemcpyAsync(W.h_status.p + i0, W.d_status.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
+        POA_CHECK(hipMemcpyAsync(W.h_next.p, W.d_next.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        POA_CHECK(hipStreamSynchronize(st));
+        bool pool_fail = false;
+        for (uint64_t i = i0; i < i1; i++)
+            if (W.h_status.p[i] == POA_ST_POOL) pool_fail = true;
+        if (pool_fail) {
+            if (nb == 1 && W.pool_scale >= 4.0) { rc_final = VGA_ERR_POOL; break; }
+            W.pool_scale = std::min(8.0, W.pool_scale * 1.7);
+            continue;  // rerun this sub-batch with a more cautious estimate
+        }
+        if (raw_est > 0) {
+            const double ratio = (double)W.h_next.p[0] / raw_est;
+            W.pool_scale = std::max(ratio * 1.15, 0.6 * W.pool_scale + 0.4 * ratio * 1.25);
+        }
+        i0 = i1;
+    }
+    vga_timer_end(ctx, t_total);
+    tr.mark("dp + traceback (sub-batches)");
+    if (rc_final != VGA_OK)
+        return vga_set_error(ctx, rc_final, "a single POA problem does not fit the %llu byte traceback pool",
+                             (unsigned long long)W.pool_size);
+    POA_CHECK(hipMemcpyAsync(W.h_score.p, W.d_score.p, n * 4, hipMemcpyDeviceToHost, st));
+    POA_CHECK(hipMemcpyAsync(W.h_row.p, W.d_row.p, n * 4, hipMemcpyDeviceToHost, st));
+    POA_CHECK(hipMemcpyAsync(W.h_nops.p, W.d_nops.p, n * 4, hipMemcpyDeviceToHost, st));
+    POA_CHECK(hipMemcpyAsync(W.h_cells.p, W.d_cells.p, n * 8, hipMemcpyDeviceToHost, st));
+    POA_CHECK(hipMemcpyAsync(W.h_vcells.p, W.d_vcells.p, n * 8, hipMemcpyDeviceToHost, st));
+    POA_CHECK(hipMemcpyAsync(W.h_ops.p, W.d_ops.p, tot_ops, hipMemcpyDeviceToHost, st));
+    POA_CHECK(hipMemcpyAsync(W.h_orow.p, W.d_orow.p, tot_ops * 4, hipMemcpyDeviceToHost, st));
+    POA_CHECK(hipStreamSynchronize(st));
+    tr.mark("D2H ops");
+    vga_timers_collect(ctx);
+
+    // ---- host: CIGAR / cs / node path from the raw op stream (reverse order on the device)
+    parallel_for(n, [&](uint64_t i) {
+        const uint32_t p = order[i];
+        poa_item &it = out[p];
+        it.ok = W.h_status.p[i] == POA_ST_OK ? 1 : 0;
+        it.score = W.h_score.p[i];
+        it.n_cells = W.h_cells.p[i];
+        it.n_vcells = W.h_vcells.p[i];
+        if (!it.ok) return;
+        const poa_prep &g = G[p];
+        const poa_prob &pb = probs[p];
+        const uint8_t *po = W.h_ops.p + pb.ops0;
+        const uint32_t *pr = W.h_orow.p + pb.ops0;
+        const char *q = views[p].query;
+        const char *bases = views[p].nodes + views[p].node_off[0];  // row r is bases[r - 1]
+        const uint32_t nops = W.h_nops.p[i];
+        std::string &cg = it.cigar, &cs = it.cs;
+        cs = "cs:Z:";
+        cg.reserve(nops / 2 + 16);
+        cs.reserve(nops / 2 + 16);
+        it.rows.reserve(g.N < nops ? g.N : nops);
+        uint64_t eq_run = 0, aligned = 0;
+        uint32_t qi = 0;
+        uint32_t t2 = nops;
+        while (t2 > 0) {
+            const uint8_t op = po[t2 - 1];
+            uint32_t u = t2, run = 0;
+            while (u > 0 && po[u - 1] == op) { u--; run++; }
+            append_u(cg, run);
+            cg.push_back(op == 0 ? 'M' : (op == 1 ? 'I' : 'D'));
+            if (op != 0 && eq_run) { cs.push_back(':'); append_u(cs, eq_run); eq_run = 0; }
+            if (op == 1) cs.push_back('+');
+            if (op == 2) cs.push_back('-');
+            for (uint32_t x = t2; x > u; x--) {
+                const uint32_t idx = x - 1;
+                if (op == 0) {
+                    const char gb = bases[pr[idx] - 1], qb = q[qi++];
+                    aligned++;
+                    if (gb == qb) eq_run++;
+                    else {
+                        if (eq_run) { cs.push_back(':'); append_u(cs, eq_run); eq_run = 0; }
+                        cs.push_back('*'); cs.push_back(lower(gb)); cs.push_back(lower(qb));
+                    }
+                    it.rows.push_back(pr[idx]);
+                } else if (op == 1) {
+                    cs.push_back(lower(q[qi++]));
+                } else {
+                    cs.push_back(lower(bases[pr[idx] - 1]));
+                    it.rows.push_back(pr[idx]);
+                }
+            }
+            t2 = u;
+        }
+        if (eq_run) { cs.push_back(':'); append_u(cs, eq_run); }
+        it.aligned = (uint32_t)aligned;
+        // rows ascend along the path: merge-walk the node table to label them
+        it.gnodes.resize(it.rows.size());
+        size_t v = 0;
+        const size_t nv = g.first_row.size();
+        for (size_t t = 0; t < it.rows.size(); t++) {
+            while (v + 1 < nv && g.first_row[v + 1] <= it.rows[t]) v++;
+            it.gnodes[t] = (uint32_t)v;
+        }
+        if (!it.rows.empty()) {
+            it.start_off = it.rows.front() - g.first_row[it.gnodes.front()];
+            it.end_off = it.rows.back() - g.first_row[it.gnodes.back()] + 1;
+        }
+    });
+    tr.mark("cigar/cs (host threads)");
+    // byte model of the DP kernel (DESIGN.md): graph bases + query + 1 direction byte per cell
+    // + the 6-byte value rows of node-end bases, written once and read back at least once
+    uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        all_cells += W.h_cells.p[i]; all_vcells += W.h_vcells.p[i]; all_ops += W.h_nops.p[i];
+        all_rows += G[i].N; all_q += G[i].qlen;
+    }
+    for (auto &a : ctx->last_times) {
+        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + 12 * all_vcells;
+        if (a.name == "poa_traceback") a.bytes = 6 * all_ops;
+    }
+    tm.ms_dp = vga_timer_sum(ctx, "poa_band_dp");
+    tm.ms_tb = vga_timer_sum(ctx, "poa_traceback");
+    tm.ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+#undef POA_CHECK
+    return VGA_OK;
+}
 
 extern "C" void vga_poa_result_free(vga_poa_result *r)
 {
@@ -850,14 +982,17 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     if (!ctx || !out || !params || (n && (!node_ptr || !node_off || !nodes_concat || !edge_ptr || !query_off || !queries_concat)))
         return VGA_ERR_ARG;
     *out = nullptr;
-    (void)hipSetDevice(ctx->device);
-    hipStream_t st = ctx->stream;
-    auto t_host0 = std::chrono::steady_clock::now();
-    vga_trace tr("poa");
-    if (params->gap_open1 < 0 || params->gap_open1 > 255 || params->gap_open2 < 0 || params->gap_open2 > 255 ||
-        params->gap_ext1 < 0 || params->gap_ext2 < 0)
-        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "gap open penalties must be in 0..255");
-
+    std::vector<poa_view> views(n);
+    for (uint64_t p = 0; p < n; p++) {
+        const uint64_t ql = query_off[p + 1] - query_off[p];
+        if (ql >= (1ull << 24)) return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query %llu too long", (unsigned long long)p);
+        views[p] = {node_off + node_ptr[p], nodes_concat, node_ptr[p + 1] - node_ptr[p], edge_src + edge_ptr[p], edge_dst + edge_ptr[p],
+                    edge_ptr[p + 1] - edge_ptr[p], queries_concat + query_off[p], (uint32_t)ql};
+    }
+    std::vector<poa_item> items;
+    poa_timing tm;
+    int rc = poa_run(ctx, views, params, items, tm);
+    if (rc != VGA_OK) return rc;
     vga_poa_result *res = (vga_poa_result *)calloc(1, sizeof(vga_poa_result));
     res->n = n;
     res->ok = pmalloc<uint8_t>(n);
@@ -871,321 +1006,10 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     res->n_rows = pmalloc<uint64_t>(n);
     res->n_cells = pmalloc<uint64_t>(n);
     res->n_value_cells = pmalloc<uint64_t>(n);
-    res->path_off[0] = res->cigar_off[0] = res->cs_off[0] = 0;
-    vga_timers_reset(ctx);
-    if (n == 0) {
-        res->abpoa_nodes = pmalloc<uint32_t>(0);
-        res->graph_nodes = pmalloc<uint32_t>(0);
-        res->cigar = pmalloc<char>(0);
-        res->cs = pmalloc<char>(0);
-        *out = res;
-        return VGA_OK;
-    }
-
-    // ---- host: build the row graphs (threads over problems)
-    std::vector<poa_graph_host> G(n);
-    std::vector<uint8_t> okprep(n, 0);
-    {
-        unsigned nt = std::thread::hardware_concurrency();
-        if (nt == 0) nt = 4;
-        if (nt > 32) nt = 32;
-        if ((uint64_t)nt > n) nt = (unsigned)n;
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++)
-            th.emplace_back([&, t]() {
-                for (uint64_t p = t; p < n; p += nt) {
-                    const uint64_t nv = node_ptr[p + 1] - node_ptr[p];
-                    const uint64_t ne = edge_ptr[p + 1] - edge_ptr[p];
-                    const uint64_t ql = query_off[p + 1] - query_off[p];
-                    if (ql >= (1ull << 18)) { okprep[p] = 0; continue; }  // 6*(qlen+1) must fit a pool chunk
-                    // node_off entries are absolute offsets into nodes_concat
-                    okprep[p] = poa_prepare(node_off + node_ptr[p], nv, nodes_concat, edge_src + edge_ptr[p],
-                                            edge_dst + edge_ptr[p], ne, (uint32_t)ql, G[p])
-                                    ? 1
-                                    : 0;
-                }
-            });
-        for (auto &x : th) x.join();
-    }
-    for (uint64_t p = 0; p < n; p++)
-        if (!okprep[p]) {
-            vga_poa_result_free(res);
-            return vga_set_error(ctx, VGA_ERR_ARG,
-                                 "vga_poa_batch: problem %llu is malformed (empty node, edge with src >= dst, in-degree > 255 "
-                                 "or query longer than 262143)",
-                                 (unsigned long long)p);
-        }
-
-    tr.mark("row graphs (host threads)");
-    // ---- flatten
-    std::vector<poa_prob> probs(n);
-    uint64_t tot_rows = 0, tot_preds = 0, tot_sink = 0, tot_q = 0, tot_ops = 0;
-    for (uint64_t p = 0; p < n; p++) {
-        poa_prob &pb = probs[p];
-        pb.row0 = tot_rows; pb.pred0 = tot_preds; pb.sink0 = tot_sink; pb.q0 = tot_q; pb.ops0 = tot_ops;
-        pb.n_sink = (uint32_t)G[p].sink.size(); pb.qlen = G[p].qlen; pb.N = G[p].N;
-        pb.w = params->wb < 0 ? G[p].qlen : (uint32_t)((int64_t)params->wb + (int64_t)(params->wf * (double)G[p].qlen));
-        tot_rows += (uint64_t)G[p].N + 1;
-        tot_preds += G[p].preds.size();
-        tot_sink += G[p].sink.size();
-        tot_q += G[p].qlen;
-        tot_ops += (uint64_t)G[p].N + G[p].qlen + 2;
-        res->n_rows[p] = G[p].N;
-    }
-    std::vector<uint4> h_meta(tot_rows);
-    std::vector<uint32_t> h_preds(tot_preds ? tot_preds : 1), h_sink(tot_sink ? tot_sink : 1);
-    std::vector<char> h_q(tot_q ? tot_q : 1);
-    for (uint64_t p = 0; p < n; p++) {
-        const poa_prob &pb = probs[p];
-        const poa_graph_host &g = G[p];
-        for (uint32_t r = 0; r <= g.N; r++)
-            h_meta[pb.row0 + r] = make_uint4((uint32_t)g.base[r] | ((uint32_t)g.flags[r] << 8) | ((uint32_t)g.npred[r] << 16),
-                                             (uint32_t)g.remain[r], g.pred_start[r], 0u);
-        if (!g.preds.empty()) memcpy(&h_preds[pb.pred0], g.preds.data(), g.preds.size() * 4);
-        if (!g.sink.empty()) memcpy(&h_sink[pb.sink0], g.sink.data(), g.sink.size() * 4);
-        if (g.qlen) memcpy(&h_q[pb.q0], queries_concat + query_off[p], g.qlen);
-    }
-
-#define POA_CHECK(call)                                                                              \
-    do {                                                                                             \
-        hipError_t e_ = (call);                                                                      \
-        if (e_ != hipSuccess) {                                                                      \
-            vga_poa_result_free(res);                                                                \
-            return vga_set_error(ctx, VGA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
-                                 __LINE__);                                                          \
-        }                                                                                            \
-    } while (0)
-
-    tr.mark("flatten");
-    if (!ctx->poa_ws) {
-        ctx->poa_ws = new poa_ws();
-        ctx->poa_ws_free = [](void *q) { delete (poa_ws *)q; };
-    }
-    poa_ws &W_ = *(poa_ws *)ctx->poa_ws;
-    auto &d_probs = W_.d_probs; auto &d_meta = W_.d_meta; auto &d_ops = W_.d_ops;
-    auto &d_beg = W_.d_beg; auto &d_end = W_.d_end; auto &d_lmax = W_.d_lmax; auto &d_rmax = W_.d_rmax;
-    auto &d_score = W_.d_score; auto &d_status = W_.d_status; auto &d_preds = W_.d_preds;
-    auto &d_sink = W_.d_sink; auto &d_row = W_.d_row; auto &d_orow = W_.d_orow; auto &d_nops = W_.d_nops; auto &d_doff = W_.d_doff;
-    auto &d_voff = W_.d_voff; auto &d_cells = W_.d_cells; auto &d_vcells = W_.d_vcells; auto &d_q = W_.d_q; auto &d_next = W_.d_next;
-    POA_CHECK(d_probs.reserve(n)); POA_CHECK(d_meta.reserve(tot_rows));
-    POA_CHECK(d_preds.reserve(h_preds.size())); POA_CHECK(d_sink.reserve(h_sink.size())); POA_CHECK(d_q.reserve(h_q.size()));
-    POA_CHECK(d_beg.reserve(tot_rows)); POA_CHECK(d_end.reserve(tot_rows)); POA_CHECK(d_doff.reserve(tot_rows));
-    POA_CHECK(d_voff.reserve(tot_rows)); POA_CHECK(d_lmax.reserve(tot_rows)); POA_CHECK(d_rmax.reserve(tot_rows));
-    POA_CHECK(d_score.reserve(n)); POA_CHECK(d_status.reserve(n)); POA_CHECK(d_row.reserve(n)); POA_CHECK(d_cells.reserve(n)); POA_CHECK(d_vcells.reserve(n));
-    POA_CHECK(d_ops.reserve(tot_ops)); POA_CHECK(d_orow.reserve(tot_ops)); POA_CHECK(d_nops.reserve(n));
-    POA_CHECK(d_next.reserve(1));
-    POA_CHECK(hipMemcpyAsync(d_probs.p, probs.data(), n * sizeof(poa_prob), hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(d_meta.p, h_meta.data(), tot_rows * sizeof(uint4), hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(d_preds.p, h_preds.data(), h_preds.size() * 4, hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(d_sink.p, h_sink.data(), h_sink.size() * 4, hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(d_q.p, h_q.data(), h_q.size(), hipMemcpyHostToDevice, st));
-
-    tr.mark("reserve + H2D enqueue");
-    // ---- pool: persistent in the ctx, sized for this batch's estimated need (capped by free HBM) and only
-    // ever grown.  Problems run in sub-batches that fit it.
-    auto est_bytes = [&](uint64_t p) -> uint64_t {
-        const poa_graph_host &g = G[p];
-        uint64_t w = params->wb < 0 ? g.qlen : (uint64_t)params->wb + (uint64_t)(params->wf * (double)g.qlen);
-        int64_t excess = (int64_t)g.remain[0] - (int64_t)g.qlen;
-        if (excess < 0) excess = -excess;
-        uint64_t width = std::min<uint64_t>((uint64_t)g.qlen + 1, 2 * w + 1 + (uint64_t)excess + 64);
-        return (uint64_t)((double)g.N * (double)width * 2.6) + 4 * POA_CHUNK;
-    };
-    {
-        uint64_t want = 0, biggest = 0;
-        for (uint64_t p = 0; p < n; p++) { uint64_t e = est_bytes(p); want += e; biggest = std::max(biggest, e); }
-        want = (uint64_t)((double)want * 1.15) + 64 * POA_CHUNK;
-        const char *env_pool = getenv("VGA_POOL_BYTES");
-        if (env_pool) want = std::min<uint64_t>(want, strtoull(env_pool, nullptr, 10));
-        if (W_.pool_size < want) {
-            size_t free_b = 0, total_b = 0;
-            POA_CHECK(hipMemGetInfo(&free_b, &total_b));
-            uint64_t avail = (uint64_t)((double)(free_b + W_.pool_size) * 0.85);
-            uint64_t target = std::min(want, avail) & ~(POA_CHUNK - 1);
-            if (target > W_.pool_size) {
-                if (W_.pool) { (void)hipFree(W_.pool); W_.pool = nullptr; W_.pool_size = 0; }
-                if (target < 64 * POA_CHUNK) {
-                    vga_poa_result_free(res);
-                    return vga_set_error(ctx, VGA_ERR_NOMEM, "vga_poa_batch: only %llu bytes of HBM free for the traceback pool",
-                                         (unsigned long long)free_b);
-                }
-                POA_CHECK(hipMalloc((void **)&W_.pool, target));
-                W_.pool_size = target;
-            }
-        }
-    }
-    uint8_t *d_pool = W_.pool;
-    const uint64_t pool_size = W_.pool_size;
-    tr.mark("pool hipMalloc");
-    poa_dev_params P;
-    P.match = params->match; P.mismatch = params->mismatch; P.o1 = params->gap_open1; P.e1 = params->gap_ext1;
-    P.o2 = params->gap_open2; P.e2 = params->gap_ext2; P.banded = params->wb >= 0;
-
-    std::vector<int32_t> h_status(n), h_score(n);
-    std::vector<uint32_t> h_row(n), h_nops(n);
-    std::vector<uint64_t> h_cells(n), h_vcells(n);
-    std::vector<uint8_t> h_ops(tot_ops);
-    std::vector<uint32_t> h_orow(tot_ops);
-
-    int t_total = vga_timer_begin(ctx, "poa_total", 0);
-    uint64_t p0 = 0;
-    double shrink = 1.0;
-    int rc_final = VGA_OK;
-    while (p0 < n) {
-        uint64_t budget = (uint64_t)((double)pool_size * 0.9 * shrink), used = 0, p1 = p0;
-        while (p1 < n) {
-            uint64_t e = est_bytes(p1);
-            if (p1 > p0 && used + e > budget) break;
-            used += e;
-            p1++;
-        }
-        const uint32_t nb = (uint32_t)(p1 - p0);
-        POA_CHECK(hipMemsetAsync(d_next.p, 0, sizeof(unsigned long long), st));
-        int t_dp = vga_timer_begin(ctx, "poa_band_dp", 0);
-        POA_CHECK(hipMemcpyAsync(d_probs.p + p0, probs.data() + p0, nb * sizeof(poa_prob), hipMemcpyHostToDevice, st));
-        {
-            uint32_t max_q = 0;
-            for (uint64_t p = p0; p < p1; p++) max_q = std::max(max_q, G[p].qlen);
-            const uint32_t lds_cols = max_q + 1;
-            const char *force = getenv("VGA_POA_KERNEL");  // "gmem" | "lds256" | "lds512" | "lds1024" (testing)
-            int nt = max_q >= 1536 ? 512 : 256;
-            bool use_lds = poa_lds_bytes(lds_cols, nt) <= 160 * 1024 - 256;
-            if (force) {
-                if (!strcmp(force, "gmem")) use_lds = false;
-                else if (!strcmp(force, "lds256")) nt = 256;
-                else if (!strcmp(force, "lds512")) nt = 512;
-                else if (!strcmp(force, "lds1024")) nt = 1024;
-                if (strcmp(force, "gmem") && poa_lds_bytes(lds_cols, nt) > 160 * 1024 - 256) use_lds = false;
-            }
-#define POA_ARGS d_probs.p + p0, d_q.p, d_meta.p, d_preds.p, d_sink.p, P, d_beg.p, \
-                 d_end.p, d_doff.p, d_voff.p, d_lmax.p, d_rmax.p, d_pool, d_next.p, pool_size, d_score.p + p0, d_row.p + p0,        \
-                 d_status.p + p0, d_cells.p + p0, d_vcells.p + p0
-            if (!use_lds) {
-                hipLaunchKernelGGL(k_poa_dp<256>, dim3(nb), dim3(256), 0, st, POA_ARGS);
-            } else {
-                const size_t lds = poa_lds_bytes(lds_cols, nt);
-                if (nt == 256) {
-                    POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL(k_poa_dp_lds<256>, dim3(nb), dim3(256), lds, st, POA_ARGS, lds_cols);
-                } else if (nt == 512) {
-                    POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL(k_poa_dp_lds<512>, dim3(nb), dim3(512), lds, st, POA_ARGS, lds_cols);
-                } else {
-                    POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL(k_poa_dp_lds<1024>, dim3(nb), dim3(1024), lds, st, POA_ARGS, lds_cols);
-                }
-            }
-#undef POA_ARGS
-            POA_CHECK(hipGetLastError());
-        }
-        vga_timer_end(ctx, t_dp);
-        int t_tb = vga_timer_begin(ctx, "poa_traceback", 0);
-        hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, d_probs.p + p0, d_meta.p, d_preds.p, d_beg.p, d_end.p, d_doff.p, d_pool, d_row.p + p0, d_status.p + p0, d_ops.p,
-                           d_orow.p, d_nops.p + p0);
-        vga_timer_end(ctx, t_tb);
-        POA_CHECK(hipMemcpyAsync(h_status.data() + p0, d_status.p + p0, nb * 4, hipMemcpyDeviceToHost, st));
-        POA_CHECK(hipStreamSynchronize(st));
-        bool pool_fail = false;
-        for (uint64_t p = p0; p < p1; p++)
-            if (h_status[p] == POA_ST_POOL) pool_fail = true;
-        if (pool_fail) {
-            if (nb == 1) { rc_final = VGA_ERR_POOL; break; }
-            shrink *= 0.5;
-            continue;  // rerun this sub-batch with fewer problems
-        }
-        p0 = p1;
-    }
-    tr.mark("dp + traceback (sub-batches)");
-    vga_timer_end(ctx, t_total);
-    if (rc_final != VGA_OK) {
-        vga_poa_result_free(res);
-        return vga_set_error(ctx, rc_final, "vga_poa_batch: a single problem does not fit the %llu byte traceback pool",
-                             (unsigned long long)pool_size);
-    }
-    POA_CHECK(hipMemcpyAsync(h_score.data(), d_score.p, n * 4, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(h_row.data(), d_row.p, n * 4, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(h_nops.data(), d_nops.p, n * 4, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(h_cells.data(), d_cells.p, n * 8, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(h_vcells.data(), d_vcells.p, n * 8, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(h_ops.data(), d_ops.p, tot_ops, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(h_orow.data(), d_orow.p, tot_ops * 4, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipStreamSynchronize(st));
-    tr.mark("D2H ops");
-    vga_timers_collect(ctx);
-
-    // ---- host: CIGAR / cs / node path from the raw op stream (reverse order on the device)
-    std::vector<std::string> cig(n), css(n);
-    std::vector<std::vector<uint32_t>> prow(n);
-    {
-        unsigned nt = std::thread::hardware_concurrency();
-        if (nt == 0) nt = 4;
-        if (nt > 32) nt = 32;
-        if ((uint64_t)nt > n) nt = (unsigned)n;
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++)
-            th.emplace_back([&, t]() {
-                for (uint64_t p = t; p < n; p += nt) {
-                    res->ok[p] = h_status[p] == POA_ST_OK ? 1 : 0;
-                    res->best_score[p] = h_score[p];
-                    res->n_cells[p] = h_cells[p];
-                    res->n_value_cells[p] = h_vcells[p];
-                    res->aln_start_offset[p] = res->aln_end_offset[p] = res->n_aligned_bases[p] = 0;
-                    if (!res->ok[p]) continue;
-                    const poa_graph_host &g = G[p];
-                    const uint8_t *po = &h_ops[probs[p].ops0];
-                    const uint32_t *pr = &h_orow[probs[p].ops0];
-                    const char *q = queries_concat + query_off[p];
-                    const uint32_t nops = h_nops[p];
-                    std::string &cg = cig[p], &cs = css[p];
-                    cs = "cs:Z:";
-                    uint64_t eq_run = 0, aligned = 0;
-                    uint32_t qi = 0;  // next query base
-                    uint32_t t2 = nops;
-                    while (t2 > 0) {
-                        const uint8_t op = po[t2 - 1];
-                        uint32_t u = t2, run = 0;
-                        while (u > 0 && po[u - 1] == op) { u--; run++; }
-                        append_u(cg, run);
-                        cg.push_back(op == 0 ? 'M' : (op == 1 ? 'I' : 'D'));
-                        if (op != 0 && eq_run) { cs.push_back(':'); append_u(cs, eq_run); eq_run = 0; }
-                        if (op == 1) cs.push_back('+');
-                        if (op == 2) cs.push_back('-');
-                        for (uint32_t x = t2; x > u; x--) {
-                            const uint32_t idx = x - 1;
-                            if (op == 0) {
-                                const char gb = (char)g.base[pr[idx]], qb = q[qi++];
-                                aligned++;
-                                if (gb == qb) eq_run++;
-                                else {
-                                    if (eq_run) { cs.push_back(':'); append_u(cs, eq_run); eq_run = 0; }
-                                    cs.push_back('*'); cs.push_back(lower(gb)); cs.push_back(lower(qb));
-                                }
-                                prow[p].push_back(pr[idx]);
-                            } else if (op == 1) {
-                                cs.push_back(lower(q[qi++]));
-                            } else {
-                                cs.push_back(lower((char)g.base[pr[idx]]));
-                                prow[p].push_back(pr[idx]);
-                            }
-                        }
-                        t2 = u;
-                    }
-                    if (eq_run) { cs.push_back(':'); append_u(cs, eq_run); }
-                    res->n_aligned_bases[p] = (uint32_t)aligned;
-                    if (!prow[p].empty()) {
-                        uint32_t fr = prow[p].front(), lr = prow[p].back();
-                        res->aln_start_offset[p] = fr - g.first_row[g.row_node[fr]];
-                        res->aln_end_offset[p] = lr - g.first_row[g.row_node[lr]] + 1;
-                    }
-                }
-            });
-        for (auto &x : th) x.join();
-    }
-    tr.mark("cigar/cs (host threads)");
     uint64_t tp = 0, tc = 0, ts = 0;
     for (uint64_t p = 0; p < n; p++) {
         res->path_off[p] = tp; res->cigar_off[p] = tc; res->cs_off[p] = ts;
-        tp += prow[p].size(); tc += cig[p].size() + 1; ts += css[p].size() + 1;
+        tp += items[p].rows.size(); tc += items[p].cigar.size() + 1; ts += items[p].cs.size() + 1;
     }
     res->path_off[n] = tp; res->cigar_off[n] = tc; res->cs_off[n] = ts;
     res->abpoa_nodes = pmalloc<uint32_t>(tp);
@@ -1193,29 +1017,20 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     res->cigar = pmalloc<char>(tc);
     res->cs = pmalloc<char>(ts);
     for (uint64_t p = 0; p < n; p++) {
-        for (size_t t = 0; t < prow[p].size(); t++) {
-            res->abpoa_nodes[res->path_off[p] + t] = prow[p][t];
-            res->graph_nodes[res->path_off[p] + t] = G[p].row_node[prow[p][t]];
+        const poa_item &it = items[p];
+        res->ok[p] = it.ok; res->best_score[p] = it.score; res->aln_start_offset[p] = it.start_off;
+        res->aln_end_offset[p] = it.end_off; res->n_aligned_bases[p] = it.aligned; res->n_rows[p] = it.n_rows;
+        res->n_cells[p] = it.n_cells; res->n_value_cells[p] = it.n_vcells;
+        if (!it.rows.empty()) {
+            memcpy(res->abpoa_nodes + res->path_off[p], it.rows.data(), it.rows.size() * 4);
+            memcpy(res->graph_nodes + res->path_off[p], it.gnodes.data(), it.gnodes.size() * 4);
         }
-        memcpy(res->cigar + res->cigar_off[p], cig[p].c_str(), cig[p].size() + 1);
-        memcpy(res->cs + res->cs_off[p], css[p].c_str(), css[p].size() + 1);
+        memcpy(res->cigar + res->cigar_off[p], it.cigar.c_str(), it.cigar.size() + 1);
+        memcpy(res->cs + res->cs_off[p], it.cs.c_str(), it.cs.size() + 1);
     }
-    // byte model for the DP kernel: N + L + C direction bytes + 12 B per node-end cell ...
-    res->ms_dp = vga_timer_sum(ctx, "poa_band_dp");
-    res->ms_traceback = vga_timer_sum(ctx, "poa_traceback");
-    res->ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
-    // byte model of the DP kernel (DESIGN.md): graph bases + query + 1 direction byte per cell
-    // + the 6-byte value rows of node-end bases, written once and read back at least once
-    uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
-    for (uint64_t p = 0; p < n; p++) {
-        all_cells += h_cells[p]; all_vcells += h_vcells[p]; all_rows += G[p].N; all_q += G[p].qlen; all_ops += h_nops[p];
-    }
-    for (auto &a : ctx->last_times) {
-        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + 12 * all_vcells;
-        if (a.name == "poa_traceback") a.bytes = 6 * all_ops;
-    }
-#undef POA_CHECK
-    tr.mark("pack results");
+    res->ms_dp = tm.ms_dp;
+    res->ms_traceback = tm.ms_tb;
+    res->ms_total = tm.ms_total;
     *out = res;
     return VGA_OK;
 }

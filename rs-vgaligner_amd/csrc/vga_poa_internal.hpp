@@ -1,0 +1,60 @@
+// vga_poa_internal.hpp -- the POA engine as the rest of the library sees it (vga_poa_batch and vga_align_batch
+// are both thin packers around poa_run).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "vga_common.hpp"
+
+// one create_align_safe(nodes, edges, query, Global) problem, by reference
+struct poa_view {
+    const uint64_t *node_off;  // n_nodes + 1 offsets into `nodes`
+    const char *nodes;
+    uint64_t n_nodes;
+    const uint32_t *esrc, *edst;  // 0-based node indices, src < dst
+    uint64_t n_edges;
+    const char *query;
+    uint32_t qlen;
+};
+
+struct poa_item {
+    uint8_t ok = 0;
+    int32_t score = 0;
+    uint32_t start_off = 0, end_off = 0, aligned = 0;
+    uint64_t n_rows = 0, n_cells = 0, n_vcells = 0;
+    std::vector<uint32_t> rows;    // AbpoaAlignmentResult.abpoa_nodes: 1-based base-row id per graph-consuming column
+    std::vector<uint32_t> gnodes;  // AbpoaAlignmentResult.graph_nodes
+    std::string cigar, cs;
+};
+
+struct poa_timing {
+    float ms_dp = 0, ms_tb = 0, ms_total = 0;
+};
+
+// Runs every problem on the GPU (sub-batched to fit the pool).  Returns VGA_OK or a negative VGA_ERR_*.
+int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_params *params, std::vector<poa_item> &out,
+            poa_timing &tm);
+
+// pinned, grow-only host staging buffer
+template <typename T>
+struct vga_hbuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    ~vga_hbuf()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+};
