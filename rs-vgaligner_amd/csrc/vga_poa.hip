@@ -16,7 +16,7 @@
 //   value row      : int32 H + two 1-byte clamped gap deltas per cell, kept only for the LAST base of every graph
 //                    node (the only rows a later, non-adjacent row can depend on) and the source row;
 //   row arrays     : 40 B per row (beg, end, direction offset, value offset, leftmost/rightmost max column,
-//                    predecessor-list slice).
+//                    predecessor row or predecessor-list slice).
 // The deltas: a successor only ever needs max(H - (O+E), Ek - E); storing d = min(H - Ek, O) keeps exactly that
 // quantity (H - E - d) and the open/extend decision (d == O) in one byte.
 //
@@ -59,14 +59,6 @@ struct poa_dev_params {
     int32_t match, mismatch, o1, e1, o2, e2, banded;
 };
 
-__device__ __forceinline__ int poa_sub(const poa_dev_params &P, uint8_t g, uint8_t q)
-{
-    const bool ga = (g == 'A') | (g == 'C') | (g == 'G') | (g == 'T');
-    const bool qa = (q == 'A') | (q == 'C') | (q == 'G') | (q == 'T');
-    if (!(ga && qa)) return 0;
-    return g == q ? P.match : -P.mismatch;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // K4.  * The row that was just filled stays in LDS, indexed by ABSOLUTE query column and overwritten in place
 //        by the next row:  Hs[j] int32 (H), Ds[j] uint16 (d1 | d2 << 8); the common predecessor (the row directly
@@ -105,7 +97,7 @@ __device__ __forceinline__ int poa_wave_scan_max(int v)
 }
 __device__ __forceinline__ int poa_wave_shr1(int v) { return poa_dpp<0x138, 0xf>(POA_IDENT, v); }  // wave_shr:1
 
-template <int NT, int CPT>
+template <int NT, int CPT, bool STAMP = false>
 __global__ __launch_bounds__(NT) void k_poa_dp_lds(
     const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
     const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
@@ -113,7 +105,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
     int32_t *row_rmax, uint2 *row_info,
     uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size, int32_t *__restrict__ out_score,
     uint32_t *__restrict__ out_row, int32_t *__restrict__ out_status, uint64_t *__restrict__ out_cells,
-    uint64_t *__restrict__ out_vcells, uint32_t lds_cols)
+    uint64_t *__restrict__ out_vcells, uint32_t lds_cols, unsigned long long *stamps = nullptr)
 {
     static_assert(CPT == 4, "row storage is 4-column aligned");
     constexpr int NW = NT / 64;
@@ -137,16 +129,29 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
     const char *query = queries + pb.q0;
     const uint4 *ntab = node_tab + pb.node0;  // {first_row, len | npred << 24, remain_last, pred_start}: one scalar load per node
     const uint32_t *plist = preds + pb.pred0;
-    volatile int32_t *vbeg = row_beg + pb.row0;
-    volatile int32_t *vend = row_end + pb.row0;
-    volatile uint64_t *vvoff = row_voff + pb.row0;
-    volatile int32_t *vlmax = row_lmax + pb.row0;
-    volatile int32_t *vrmax = row_rmax + pb.row0;
+    // Plain (non-volatile) accesses: a volatile store makes hipcc wait vmcnt(0) first, i.e. for every direction-byte
+    // store still in flight.  Cross-wave visibility of these arrays is only needed by "far" rows and by the sink
+    // evaluation, both of which sit behind a full __syncthreads().
+    int32_t *vbeg = row_beg + pb.row0;
+    int32_t *vend = row_end + pb.row0;
+    uint64_t *vvoff = row_voff + pb.row0;
+    int32_t *vlmax = row_lmax + pb.row0;
+    int32_t *vrmax = row_rmax + pb.row0;
     uint64_t *gdoff = row_doff + pb.row0;
     uint2 *ginfo = row_info + pb.row0;
 
     const int o1 = P.o1, e1 = P.e1, o2 = P.o2, e2 = P.e2;
     const int bw = (int)pb.w;
+    // diagnostic build only (STAMP): cycles per row segment, summed over the rows of this workgroup's wave 0 / last wave
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, n_far = 0, n_multi = 0, n_rows = 0, n_steps = 0;
+    auto stamp = [&](int seg) {
+        if constexpr (STAMP) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            if (seg >= 0) tacc[seg] += t - tprev;
+            tprev = t;
+        }
+    };
 
     uint64_t dcur = 0, dend = 0, vcur = 0, vendp = 0;
     bool failed = false;
@@ -167,11 +172,19 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
         return r;
     };
 
-    for (int t = tid; t < qlen; t += NT) Qs[t] = (uint8_t)query[t];
+    for (int t = tid; t < (int)lds_cols; t += NT) {
+        uint8_t code = 4;
+        if (t < qlen) {
+            const char ch = query[t];
+            code = ch == 'A' ? 0 : (ch == 'C' ? 1 : (ch == 'G' ? 2 : (ch == 'T' ? 3 : 4)));
+        }
+        Qs[t] = code;  // 0..3 = ACGT, 4 = anything else (scores 0 against everything)
+    }
     __syncthreads();
 
     int prev_beg = 0, prev_end = -1, prev_lmax = 0, prev_rmax = 0;
     uint64_t cells = 0, vcells = 0;
+    uint32_t seq_word = 0, seq_word_idx = 0xFFFFFFFFu;
 
     // Rows are generated from the node table: node 0 is the virtual source (one row, no predecessor), node v
     // (v >= 1) contributes len rows whose first has the node's predecessor list and whose others follow the row
@@ -188,12 +201,19 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
         const int remain = (int)nt.z + (int)(nlen - 1 - tn);
         uint8_t gb = 0;
         if (v > 0) {
-            const uint64_t sb = pb.seq0 + (uint64_t)(r - 1);  // row r is base r-1 of the problem's node sequences
-            gb = (uint8_t)(seq32[sb >> 2] >> (8u * (uint32_t)(sb & 3u)));
+            // row r is base r-1 of the problem's node sequences (seq0 is 4-aligned): one scalar dword per 4 rows
+            const uint32_t bi = r - 1;
+            if ((bi & 3u) == 0 || (bi >> 2) != seq_word_idx) { seq_word_idx = bi >> 2; seq_word = seq32[(pb.seq0 >> 2) + seq_word_idx]; }
+            gb = (uint8_t)(seq_word >> (8u * (bi & 3u)));
         }
+        // nt.w is the predecessor ROW itself for a node with one predecessor, the slice start in `preds` otherwise
         bool far = false;
-        if (first)
-            for (int t = 0; t < np; t++) far |= plist[ps + t] != r - 1;
+        if (first) {
+            if (np == 1) far = ps != r - 1;
+            else
+                for (int t = 0; t < np; t++) far |= plist[ps + t] != r - 1;
+        }
+        stamp(-1);
         if (far) __syncthreads();  // vmcnt(0) + barrier: the value rows / row arrays of far predecessors have landed
         int mpl, mpr;
         if (r == 0) { mpl = 0; mpr = 0; }
@@ -201,7 +221,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
         else {
             mpl = INT32_MAX; mpr = 0;
             for (int t = 0; t < np; t++) {
-                const uint32_t p = plist[ps + t];
+                const uint32_t p = np == 1 ? ps : plist[ps + t];
                 int lm, rm;
                 if (p == r - 1) { lm = prev_lmax + 1; rm = prev_rmax + 1; }
                 else { lm = vlmax[p] + 1; rm = vrmax[p] + 1; }
@@ -233,10 +253,16 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
             vvoff[r] = voff;
             ginfo[r] = make_uint2(ps, first ? (uint32_t)np : 0u);
         }
-        int32_t *Hrow = (int32_t *)(pool + voff);
-        uint8_t *d1row = pool + voff + 4ull * (uint64_t)W;
-        uint8_t *d2row = d1row + W;
+        int32_t *Hrow = (int32_t *)(pool + voff);                       // value row: int32 H[W] then uint16 D[W]
+        uint16_t *Drow = (uint16_t *)(pool + voff + 4ull * (uint64_t)W);
         uint8_t *drow = pool + doff;
+        // substitution score of this row's base against a query CODE (0..3 = ACGT, 4 = anything else)
+        const int gcode = gb == 'A' ? 0 : (gb == 'C' ? 1 : (gb == 'G' ? 2 : (gb == 'T' ? 3 : 4)));
+        const int sc_eq = gcode == 4 ? 0 : P.match, sc_ne = gcode == 4 ? 0 : -P.mismatch;
+        // single predecessor = the row directly above (in LDS): the branch-free fast path applies
+        const bool single_lds = r > 0 && np == 1 && !far;
+        stamp(0);  // row prologue (band, allocation, metadata)
+        if constexpr (STAMP) { n_far += far; n_multi += np > 1; n_rows++; n_steps += (W + STEP - 1) / STEP; }
 
         int carry1 = POA_IDENT, carry2 = POA_IDENT, left1 = POA_IDENT, left2 = POA_IDENT;
         int best = INT32_MIN, lpos = beg, rpos = beg;
@@ -245,185 +271,289 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
             const int c = c0 + CPT * tid;   // storage index of this lane's first cell (multiple of 4)
             const int j0 = bal + c;         // absolute column of this lane's first cell (multiple of 4)
             const bool lane_act = j0 <= end;  // j0 + CPT - 1 >= beg always holds (bal > beg - 4)
+            const int nw_step = (W - c0 + 64 * CPT - 1) / (64 * CPT) < NW ? (W - c0 + 64 * CPT - 1) / (64 * CPT) : NW;
+            const bool wave_act = wv < nw_step;
+            const bool fast = single_lds && wave_act;  // lean branch-free path (band edges handled by masks)
             int ht[CPT], hts[CPT], ev1[CPT], ev2[CPT], pmv[CPT], p1v[CPT], p2v[CPT], ofl[CPT];
-            bool act[CPT];
-#pragma unroll
-            for (int k = 0; k < CPT; k++) {
-                const int j = j0 + k;
-                act[k] = j >= beg && j <= end;
-                ht[k] = POA_NEG; hts[k] = 0; ev1[k] = POA_NEG; ev2[k] = POA_NEG; pmv[k] = 0; p1v[k] = 0; p2v[k] = 0; ofl[k] = 0;
-            }
-            if (r == 0) {
-#pragma unroll
-                for (int k = 0; k < CPT; k++) ht[k] = (j0 + k == 0) ? 0 : POA_NEG;
-            } else if (lane_act) {
-                int sub[CPT], m[CPT];
-                {
-                    // query bases j0-1 .. j0+CPT-2 (column j consumes query[j-1])
-                    const uint32_t qw = *(const uint32_t *)(Qs + j0);  // Qs[j0..j0+3]
-                    const uint8_t qm1 = j0 >= 1 ? Qs[j0 - 1] : (uint8_t)0;
-#pragma unroll
-                    for (int k = 0; k < CPT; k++) {
-                        const uint8_t qc = k == 0 ? qm1 : (uint8_t)(qw >> (8 * (k - 1)));
-                        sub[k] = poa_sub(P, gb, (j0 + k >= 1) ? qc : (uint8_t)0);
-                        m[k] = POA_NEG;
-                    }
-                }
-                for (int t = 0; t < np; t++) {
-                    const uint32_t p = first ? plist[ps + t] : r - 1;
-                    int hj[CPT], dj[CPT], hm0;
-                    int bp, ep;
-                    if (p == r - 1) {
-                        bp = prev_beg; ep = prev_end;
-                        const int4 hv = *(const int4 *)(Hs + j0);
-                        const uint2 dv = *(const uint2 *)(Ds + j0);
-                        hj[0] = hv.x; hj[1] = hv.y; hj[2] = hv.z; hj[3] = hv.w;
-                        dj[0] = dv.x & 0xffff; dj[1] = dv.x >> 16; dj[2] = dv.y & 0xffff; dj[3] = dv.y >> 16;
-                        if (tid == NT - 1) edgeH[buf] = hv.w;   // old value of this step's last column
-                        hm0 = POA_NEG;
-                        if (j0 >= 1) hm0 = (tid == 0 && c0 > 0) ? edgeH[buf ^ 1] : Hs[j0 - 1];
-                    } else {
-                        bp = vbeg[p]; ep = vend[p];
-                        const uint64_t pv = vvoff[p];
-                        const int balp = bp & ~3;
-                        const int Wp = (ep - balp + 1 + 3) & ~3;
-                        const int32_t *Hp = (const int32_t *)(pool + pv);
-                        const uint8_t *d1p = pool + pv + 4ull * (uint64_t)Wp;
-                        const uint8_t *d2p = d1p + Wp;
-#pragma unroll
-                        for (int k = 0; k < CPT; k++) {
-                            const int j = j0 + k;
-                            hj[k] = POA_NEG; dj[k] = 0;
-                            if (j >= bp && j <= ep) { hj[k] = Hp[j - balp]; dj[k] = (int)d1p[j - balp] | ((int)d2p[j - balp] << 8); }
-                        }
-                        hm0 = POA_NEG;
-                        if (j0 - 1 >= bp && j0 - 1 <= ep) hm0 = Hp[j0 - 1 - balp];
-                    }
-#pragma unroll
-                    for (int k = 0; k < CPT; k++) {
-                        const int j = j0 + k;
-                        const int hm = k == 0 ? hm0 : hj[k - 1];
-                        if (act[k] && j >= 1 && j - 1 >= bp && j - 1 <= ep) {
-                            const int cnd = hm + sub[k];
-                            if (cnd > m[k]) { m[k] = cnd; pmv[k] = t; }
-                        }
-                        if (act[k] && j >= bp && j <= ep) {
-                            const int dd1 = dj[k] & 255, dd2 = dj[k] >> 8;
-                            const int c1 = hj[k] - e1 - dd1;
-                            if (c1 > ev1[k]) { ev1[k] = c1; p1v[k] = t; ofl[k] = (ofl[k] & 2) | (dd1 == o1 ? 1 : 0); }
-                            const int c2 = hj[k] - e2 - dd2;
-                            if (c2 > ev2[k]) { ev2[k] = c2; p2v[k] = t; ofl[k] = (ofl[k] & 1) | (dd2 == o2 ? 2 : 0); }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < CPT; k++) {
-                    ht[k] = m[k];
-                    if (ev1[k] > ht[k]) { ht[k] = ev1[k]; hts[k] = 1; }
-                    if (ev2[k] > ht[k]) { ht[k] = ev2[k]; hts[k] = 2; }
-                }
-            }
-            // ---- insertion recurrence: serial inside the lane, scan of the lane aggregates across the wave
             int a1[CPT], a2[CPT];
             int agg1 = POA_IDENT, agg2 = POA_IDENT;
-#pragma unroll
-            for (int k = 0; k < CPT; k++) {
-                a1[k] = act[k] ? ht[k] + e1 * (j0 + k) : POA_IDENT;
-                a2[k] = act[k] ? ht[k] + e2 * (j0 + k) : POA_IDENT;
-                agg1 = a1[k] > agg1 ? a1[k] : agg1;
-                agg2 = a2[k] > agg2 ? a2[k] : agg2;
-            }
-            const int i1 = poa_wave_scan_max(agg1), i2 = poa_wave_scan_max(agg2);
-            if (lane == 63) {
-                sW1[buf * NW + wv] = i1; sW2[buf * NW + wv] = i2;
-                sL1[buf * NW + wv] = a1[CPT - 1]; sL2[buf * NW + wv] = a2[CPT - 1];
-            }
-            POA_LDS_BARRIER();
-            int x1 = poa_wave_shr1(i1), x2 = poa_wave_shr1(i2);
-            int la1 = poa_wave_shr1(a1[CPT - 1]), la2 = poa_wave_shr1(a2[CPT - 1]);
-            if (lane == 0) {
-                la1 = wv == 0 ? left1 : sL1[buf * NW + wv - 1];
-                la2 = wv == 0 ? left2 : sL2[buf * NW + wv - 1];
-            }
-            int pre1 = carry1, pre2 = carry2, all1 = carry1, all2 = carry2;
-#pragma unroll
-            for (int q = 0; q < NW; q++) {
-                const int t1 = sW1[buf * NW + q], t2 = sW2[buf * NW + q];
-                if (q < wv) { pre1 = t1 > pre1 ? t1 : pre1; pre2 = t2 > pre2 ? t2 : pre2; }
-                all1 = t1 > all1 ? t1 : all1;
-                all2 = t2 > all2 ? t2 : all2;
-            }
-            int run1 = pre1 > x1 ? pre1 : x1;   // max of a1 over every column before this lane's first cell
-            int run2 = pre2 > x2 ? pre2 : x2;
-            carry1 = all1; carry2 = all2;
-            left1 = sL1[buf * NW + NW - 1]; left2 = sL2[buf * NW + NW - 1];
-            if (lane_act) {
-                int hv[CPT], codev[CPT], d1v[CPT], d2v[CPT];
+            if (fast) {
+                // ---------------- lean path, phase 1: one predecessor, the row above (LDS); masks instead of branches
+                const int4 hv = *(const int4 *)(Hs + j0);
+                const uint2 dv = *(const uint2 *)(Ds + j0);
+                const uint32_t qw = *(const uint32_t *)(Qs + j0);
+                int hm[CPT], hj[CPT], g1[CPT], g2[CPT], qc[CPT];
+                hj[0] = hv.x; hj[1] = hv.y; hj[2] = hv.z; hj[3] = hv.w;
+                if (tid == NT - 1) edgeH[buf] = hv.w;
+                const int jm1 = j0 > 0 ? j0 - 1 : 0;
+                hm[0] = (tid == 0 && c0 > 0) ? edgeH[buf ^ 1] : Hs[jm1];
+                hm[1] = hv.x; hm[2] = hv.y; hm[3] = hv.z;
+                g1[0] = dv.x & 255; g2[0] = (dv.x >> 8) & 255; g1[1] = (dv.x >> 16) & 255; g2[1] = dv.x >> 24;
+                g1[2] = dv.y & 255; g2[2] = (dv.y >> 8) & 255; g1[3] = (dv.y >> 16) & 255; g2[3] = dv.y >> 24;
+                qc[0] = Qs[jm1]; qc[1] = qw & 255; qc[2] = (qw >> 8) & 255; qc[3] = (qw >> 16) & 255;
+                const unsigned pspan = (unsigned)(prev_end - prev_beg), span = (unsigned)(end - beg);
+                bool inprev = j0 >= 1 && (unsigned)(j0 - 1 - prev_beg) <= pspan;  // column j-1 inside the predecessor's band
 #pragma unroll
                 for (int k = 0; k < CPT; k++) {
                     const int j = j0 + k;
-                    int f1 = POA_NEG, f2 = POA_NEG, fo1 = 0, fo2 = 0;
-                    if (j > beg) {
-                        f1 = run1 - o1 - e1 * j;
-                        f2 = run2 - o2 - e2 * j;
-                        fo1 = run1 == la1;
-                        fo2 = run2 == la2;
+                    const bool inj = (unsigned)(j - prev_beg) <= pspan;
+                    const bool actk = (unsigned)(j - beg) <= span;
+                    const int s = qc[k] == gcode ? sc_eq : (qc[k] == 4 ? 0 : sc_ne);
+                    const int m = inprev ? hm[k] + s : POA_NEG;
+                    ev1[k] = inj ? hj[k] - g1[k] : POA_NEG;
+                    ev2[k] = inj ? hj[k] - g2[k] : POA_NEG;
+                    const int me = m > ev1[k] ? m : ev1[k];
+                    ht[k] = me > ev2[k] ? me : ev2[k];
+                    hts[k] = ev2[k] > me ? 2 : (ev1[k] > m ? 1 : 0);
+                    ofl[k] = (g1[k] == o1 + e1 ? 1 : 0) | (g2[k] == o2 + e2 ? 2 : 0);
+                    pmv[k] = 0; p1v[k] = 0; p2v[k] = 0;
+                    a1[k] = actk ? ht[k] + e1 * j : POA_IDENT;
+                    a2[k] = actk ? ht[k] + e2 * j : POA_IDENT;
+                    agg1 = a1[k] > agg1 ? a1[k] : agg1;
+                    agg2 = a2[k] > agg2 ? a2[k] : agg2;
+                    inprev = inj;
+                }
+            } else if (wave_act) {
+                // ---------------- general path, phase 1: band edges, source row, several / far predecessors
+                bool act[CPT];
+#pragma unroll
+                for (int k = 0; k < CPT; k++) {
+                    const int j = j0 + k;
+                    act[k] = j >= beg && j <= end;
+                    ht[k] = POA_NEG; hts[k] = 0; ev1[k] = POA_NEG; ev2[k] = POA_NEG; pmv[k] = 0; p1v[k] = 0; p2v[k] = 0; ofl[k] = 0;
+                }
+                if (r == 0) {
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) ht[k] = (j0 + k == 0) ? 0 : POA_NEG;
+                } else if (lane_act) {
+                    int sub[CPT], m[CPT];
+                    {
+                        const uint32_t qw = *(const uint32_t *)(Qs + j0);  // codes of query[j0 .. j0+3]
+                        const int qm1 = j0 >= 1 ? (int)Qs[j0 - 1] : 4;
+#pragma unroll
+                        for (int k = 0; k < CPT; k++) {
+                            const int qc = k == 0 ? qm1 : (int)((qw >> (8 * (k - 1))) & 255u);
+                            sub[k] = qc == gcode ? sc_eq : (qc == 4 ? 0 : sc_ne);
+                            m[k] = POA_NEG;
+                        }
                     }
-                    int h = ht[k], hs = hts[k];
-                    if (f1 > h) { h = f1; hs = 3; }
-                    if (f2 > h) { h = f2; hs = 4; }
-                    const int lo4 = hs < 3 ? hs : 3 + (hs - 3) * 3 + hts[k];
-                    codev[k] = lo4 | (fo1 << 4) | (fo2 << 5) | ((ofl[k] & 1) << 6) | ((ofl[k] & 2) << 6);
-                    int dd1 = h - ev1[k]; dd1 = dd1 < o1 ? dd1 : o1;
-                    int dd2 = h - ev2[k]; dd2 = dd2 < o2 ? dd2 : o2;
-                    hv[k] = h; d1v[k] = dd1; d2v[k] = dd2;
-                    if (act[k]) {
-                        if (h > best) { best = h; lpos = j; rpos = j; }
-                        else if (h == best) rpos = j;
-                        run1 = a1[k] > run1 ? a1[k] : run1;
+                    for (int t = 0; t < np; t++) {
+                        const uint32_t p = first ? (np == 1 ? ps : plist[ps + t]) : r - 1;
+                        int hj[CPT], dj[CPT], hm0;
+                        int bp, ep;
+                        if (p == r - 1) {
+                            bp = prev_beg; ep = prev_end;
+                            const int4 hv = *(const int4 *)(Hs + j0);
+                            const uint2 dv = *(const uint2 *)(Ds + j0);
+                            hj[0] = hv.x; hj[1] = hv.y; hj[2] = hv.z; hj[3] = hv.w;
+                            dj[0] = dv.x & 0xffff; dj[1] = dv.x >> 16; dj[2] = dv.y & 0xffff; dj[3] = dv.y >> 16;
+                            if (tid == NT - 1) edgeH[buf] = hv.w;   // old value of this step's last column
+                            hm0 = POA_NEG;
+                            if (j0 >= 1) hm0 = (tid == 0 && c0 > 0) ? edgeH[buf ^ 1] : Hs[j0 - 1];
+                        } else {
+                            bp = vbeg[p]; ep = vend[p];
+                            const uint64_t pv = vvoff[p];
+                            const int balp = bp & ~3;
+                            const int Wp = (ep - balp + 1 + 3) & ~3;
+                            const int32_t *Hp = (const int32_t *)(pool + pv);
+                            const uint16_t *Dp = (const uint16_t *)(pool + pv + 4ull * (uint64_t)Wp);
+#pragma unroll
+                            for (int k = 0; k < CPT; k++) {
+                                const int j = j0 + k;
+                                hj[k] = POA_NEG; dj[k] = 0;
+                                if (j >= bp && j <= ep) { hj[k] = Hp[j - balp]; dj[k] = (int)Dp[j - balp]; }
+                            }
+                            hm0 = POA_NEG;
+                            if (j0 - 1 >= bp && j0 - 1 <= ep) hm0 = Hp[j0 - 1 - balp];
+                        }
+#pragma unroll
+                        for (int k = 0; k < CPT; k++) {
+                            const int j = j0 + k;
+                            const int hm = k == 0 ? hm0 : hj[k - 1];
+                            if (act[k] && j >= 1 && j - 1 >= bp && j - 1 <= ep) {
+                                const int cnd = hm + sub[k];
+                                if (cnd > m[k]) { m[k] = cnd; pmv[k] = t; }
+                            }
+                            if (act[k] && j >= bp && j <= ep) {
+                                const int gg1 = dj[k] & 255, gg2 = dj[k] >> 8;  // E + d
+                                const int c1 = hj[k] - gg1;
+                                if (c1 > ev1[k]) { ev1[k] = c1; p1v[k] = t; ofl[k] = (ofl[k] & 2) | (gg1 == o1 + e1 ? 1 : 0); }
+                                const int c2 = hj[k] - gg2;
+                                if (c2 > ev2[k]) { ev2[k] = c2; p2v[k] = t; ofl[k] = (ofl[k] & 1) | (gg2 == o2 + e2 ? 2 : 0); }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) {
+                        ht[k] = m[k];
+                        if (ev1[k] > ht[k]) { ht[k] = ev1[k]; hts[k] = 1; }
+                        if (ev2[k] > ht[k]) { ht[k] = ev2[k]; hts[k] = 2; }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < CPT; k++) {
+                    a1[k] = act[k] ? ht[k] + e1 * (j0 + k) : POA_IDENT;
+                    a2[k] = act[k] ? ht[k] + e2 * (j0 + k) : POA_IDENT;
+                    agg1 = a1[k] > agg1 ? a1[k] : agg1;
+                    agg2 = a2[k] > agg2 ? a2[k] : agg2;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CPT; k++) { a1[k] = POA_IDENT; a2[k] = POA_IDENT; ht[k] = POA_NEG; hts[k] = 0; ev1[k] = ev2[k] = POA_NEG; pmv[k] = p1v[k] = p2v[k] = ofl[k] = 0; }
+            }
+            stamp(1);  // phase 1
+            // ---- insertion recurrence: serial inside the lane, scan of the lane aggregates across the wave
+            int i1 = POA_IDENT, i2 = POA_IDENT;
+            if (wave_act) {
+                i1 = poa_wave_scan_max(agg1);
+                i2 = poa_wave_scan_max(agg2);
+            }
+            if (lane == 63) {  // inactive waves publish the identity, so readers need no masks
+                sW1[buf * NW + wv] = i1; sW2[buf * NW + wv] = i2;
+                sL1[buf * NW + wv] = a1[CPT - 1]; sL2[buf * NW + wv] = a2[CPT - 1];
+            }
+            stamp(2);  // scans
+            POA_LDS_BARRIER();
+            stamp(3);  // step barrier
+            int tw1[NW], tw2[NW];
+#pragma unroll
+            for (int q = 0; q < NW; q++) { tw1[q] = sW1[buf * NW + q]; tw2[q] = sW2[buf * NW + q]; }
+            int all1 = carry1, all2 = carry2;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                all1 = tw1[q] > all1 ? tw1[q] : all1;
+                all2 = tw2[q] > all2 ? tw2[q] : all2;
+            }
+            if (wave_act) {
+                int x1 = poa_wave_shr1(i1), x2 = poa_wave_shr1(i2);
+                int la1 = poa_wave_shr1(a1[CPT - 1]), la2 = poa_wave_shr1(a2[CPT - 1]);
+                if (lane == 0) {
+                    la1 = wv == 0 ? left1 : sL1[buf * NW + wv - 1];
+                    la2 = wv == 0 ? left2 : sL2[buf * NW + wv - 1];
+                }
+                int pre1 = carry1, pre2 = carry2;
+#pragma unroll
+                for (int q = 0; q < NW; q++) {
+                    if (q < wv) { pre1 = tw1[q] > pre1 ? tw1[q] : pre1; pre2 = tw2[q] > pre2 ? tw2[q] : pre2; }
+                }
+                int run1 = pre1 > x1 ? pre1 : x1;   // max of a1 over every column before this lane's first cell
+                int run2 = pre2 > x2 ? pre2 : x2;
+                int hv[CPT], codev[CPT], dpk[CPT];
+                if (fast) {
+                    // ---------------- lean path, phase 2
+                    const unsigned span = (unsigned)(end - beg);
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) {
+                        const int j = j0 + k;
+                        const bool actk = (unsigned)(j - beg) <= span;
+                        const bool hasleft = j > beg;  // the first column of the band has no insertion predecessor
+                        const int f1 = hasleft ? run1 - (o1 + e1 * j) : POA_NEG, f2 = hasleft ? run2 - (o2 + e2 * j) : POA_NEG;
+                        const int fo = hasleft ? ((run1 == la1 ? 16 : 0) | (run2 == la2 ? 32 : 0)) : 0;
+                        const int hf = ht[k] > f1 ? ht[k] : f1;
+                        const int h = hf > f2 ? hf : f2;
+                        const int lo4 = hts[k] + (f2 > hf ? 6 : (f1 > ht[k] ? 3 : 0));
+                        codev[k] = lo4 | fo | (ofl[k] << 6);
+                        int dd1 = h - ev1[k]; dd1 = (dd1 < o1 ? dd1 : o1) + e1;
+                        int dd2 = h - ev2[k]; dd2 = (dd2 < o2 ? dd2 : o2) + e2;
+                        hv[k] = h;
+                        dpk[k] = dd1 | (dd2 << 8);
+                        const int hb = actk ? h : INT32_MIN;  // inactive cells never take part in the row maximum
+                        if (hb > best) { best = hb; lpos = j; rpos = j; }
+                        else if (actk && hb == best) rpos = j;
+                        run1 = a1[k] > run1 ? a1[k] : run1;   // a1 is IDENT on inactive cells
                         run2 = a2[k] > run2 ? a2[k] : run2;
-                        la1 = a1[k]; la2 = a2[k];
+                        la1 = actk ? a1[k] : la1; la2 = actk ? a2[k] : la2;
+                    }
+                } else if (lane_act) {
+                    // ---------------- general path, phase 2
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) {
+                        const int j = j0 + k;
+                        const bool actk = j >= beg && j <= end;
+                        int f1 = POA_NEG, f2 = POA_NEG, fo1 = 0, fo2 = 0;
+                        if (j > beg) {
+                            f1 = run1 - o1 - e1 * j;
+                            f2 = run2 - o2 - e2 * j;
+                            fo1 = run1 == la1;
+                            fo2 = run2 == la2;
+                        }
+                        int h = ht[k], hs = hts[k];
+                        if (f1 > h) { h = f1; hs = 3; }
+                        if (f2 > h) { h = f2; hs = 4; }
+                        const int lo4 = hs < 3 ? hs : 3 + (hs - 3) * 3 + hts[k];
+                        codev[k] = lo4 | (fo1 << 4) | (fo2 << 5) | (ofl[k] << 6);
+                        int dd1 = h - ev1[k]; dd1 = (dd1 < o1 ? dd1 : o1) + e1;
+                        int dd2 = h - ev2[k]; dd2 = (dd2 < o2 ? dd2 : o2) + e2;
+                        hv[k] = h;
+                        dpk[k] = dd1 | (dd2 << 8);
+                        if (actk) {
+                            if (h > best) { best = h; lpos = j; rpos = j; }
+                            else if (h == best) rpos = j;
+                            run1 = a1[k] > run1 ? a1[k] : run1;
+                            run2 = a2[k] > run2 ? a2[k] : run2;
+                            la1 = a1[k]; la2 = a2[k];
+                        }
                     }
                 }
-                *(int4 *)(Hs + j0) = make_int4(hv[0], hv[1], hv[2], hv[3]);
-                *(uint2 *)(Ds + j0) = make_uint2((uint32_t)(d1v[0] | (d2v[0] << 8)) | ((uint32_t)(d1v[1] | (d2v[1] << 8)) << 16),
-                                                  (uint32_t)(d1v[2] | (d2v[2] << 8)) | ((uint32_t)(d1v[3] | (d2v[3] << 8)) << 16));
-                *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
-                if (last) {
-                    *(int4 *)(Hrow + c) = make_int4(hv[0], hv[1], hv[2], hv[3]);
-                    *(uint32_t *)(d1row + c) = (uint32_t)d1v[0] | ((uint32_t)d1v[1] << 8) | ((uint32_t)d1v[2] << 16) | ((uint32_t)d1v[3] << 24);
-                    *(uint32_t *)(d2row + c) = (uint32_t)d2v[0] | ((uint32_t)d2v[1] << 8) | ((uint32_t)d2v[2] << 16) | ((uint32_t)d2v[3] << 24);
-                }
-                if (np > 1) {
-                    *(uint32_t *)(drow + (uint64_t)W + c) = (uint32_t)pmv[0] | ((uint32_t)pmv[1] << 8) | ((uint32_t)pmv[2] << 16) | ((uint32_t)pmv[3] << 24);
-                    *(uint32_t *)(drow + 2ull * W + c) = (uint32_t)p1v[0] | ((uint32_t)p1v[1] << 8) | ((uint32_t)p1v[2] << 16) | ((uint32_t)p1v[3] << 24);
-                    *(uint32_t *)(drow + 3ull * W + c) = (uint32_t)p2v[0] | ((uint32_t)p2v[1] << 8) | ((uint32_t)p2v[2] << 16) | ((uint32_t)p2v[3] << 24);
+                if (lane_act) {
+                    const uint2 dq = make_uint2((uint32_t)dpk[0] | ((uint32_t)dpk[1] << 16), (uint32_t)dpk[2] | ((uint32_t)dpk[3] << 16));
+                    *(int4 *)(Hs + j0) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+                    *(uint2 *)(Ds + j0) = dq;
+                    *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
+                    if (last) {
+                        *(int4 *)(Hrow + c) = make_int4(hv[0], hv[1], hv[2], hv[3]);
+                        *(uint2 *)(Drow + c) = dq;
+                    }
+                    if (np > 1) {
+                        *(uint32_t *)(drow + (uint64_t)W + c) = (uint32_t)pmv[0] | ((uint32_t)pmv[1] << 8) | ((uint32_t)pmv[2] << 16) | ((uint32_t)pmv[3] << 24);
+                        *(uint32_t *)(drow + 2ull * W + c) = (uint32_t)p1v[0] | ((uint32_t)p1v[1] << 8) | ((uint32_t)p1v[2] << 16) | ((uint32_t)p1v[3] << 24);
+                        *(uint32_t *)(drow + 3ull * W + c) = (uint32_t)p2v[0] | ((uint32_t)p2v[1] << 8) | ((uint32_t)p2v[2] << 16) | ((uint32_t)p2v[3] << 24);
+                    }
                 }
             }
+            carry1 = all1; carry2 = all2;
+            left1 = sL1[buf * NW + nw_step - 1]; left2 = sL2[buf * NW + nw_step - 1];
         }
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int ob = __shfl_xor(best, d, 64), ol = __shfl_xor(lpos, d, 64), orr = __shfl_xor(rpos, d, 64);
-            if (ob > best) { best = ob; lpos = ol; rpos = orr; }
-            else if (ob == best) { lpos = ol < lpos ? ol : lpos; rpos = orr > rpos ? orr : rpos; }
+        stamp(4);  // phase 2 + stores
+        {
+            // wave-level: maximum of best, then the leftmost / rightmost column among the lanes that hold it
+            int wb = poa_wave_scan_max(best);                       // lane 63 holds the wave maximum
+            wb = __builtin_amdgcn_readlane(wb, 63);
+            int lm = best == wb ? -lpos : POA_IDENT;                 // min(lpos) = -max(-lpos)
+            int rm = best == wb ? rpos : POA_IDENT;
+            lm = poa_wave_scan_max(lm);
+            rm = poa_wave_scan_max(rm);
+            if (lane == 63) { sRed[wv * 3 + 0] = wb; sRed[wv * 3 + 1] = -lm; sRed[wv * 3 + 2] = rm; }
         }
-        if (lane == 0) { sRed[wv * 3 + 0] = best; sRed[wv * 3 + 1] = lpos; sRed[wv * 3 + 2] = rpos; }
         POA_LDS_BARRIER();  // row complete in LDS; also fences the scratch buffers between rows
-        best = sRed[0]; lpos = sRed[1]; rpos = sRed[2];
+        {
+            int rb[NW], rl[NW], rr[NW];
 #pragma unroll
-        for (int q = 1; q < NW; q++) {
-            const int ob = sRed[q * 3], ol = sRed[q * 3 + 1], orr = sRed[q * 3 + 2];
-            if (ob > best) { best = ob; lpos = ol; rpos = orr; }
-            else if (ob == best) { lpos = ol < lpos ? ol : lpos; rpos = orr > rpos ? orr : rpos; }
+            for (int q = 0; q < NW; q++) { rb[q] = sRed[q * 3]; rl[q] = sRed[q * 3 + 1]; rr[q] = sRed[q * 3 + 2]; }
+            best = rb[0]; lpos = rl[0]; rpos = rr[0];
+#pragma unroll
+            for (int q = 1; q < NW; q++) {
+                if (rb[q] > best) { best = rb[q]; lpos = rl[q]; rpos = rr[q]; }
+                else if (rb[q] == best) { lpos = rl[q] < lpos ? rl[q] : lpos; rpos = rr[q] > rpos ? rr[q] : rpos; }
+            }
         }
+        // uniform values: keep them in scalar registers so the next row's band arithmetic runs on the scalar unit
+        lpos = __builtin_amdgcn_readfirstlane(lpos);
+        rpos = __builtin_amdgcn_readfirstlane(rpos);
         if (tid == 0) { vlmax[r] = lpos; vrmax[r] = rpos; }
         prev_beg = beg; prev_end = end; prev_lmax = lpos; prev_rmax = rpos;
+        stamp(5);  // row reduce + row barrier
     }
     }
     __syncthreads();
     if (tid == 0) {
         out_cells[blockIdx.x] = cells;
         out_vcells[blockIdx.x] = vcells;
+        if constexpr (STAMP) {
+            if (stamps && blockIdx.x < 64)
+                for (int s = 0; s < 6; s++) stamps[blockIdx.x * 6 + s] = tacc[s];
+            if (stamps && blockIdx.x == 0) { stamps[384] = n_far; stamps[385] = n_multi; stamps[386] = n_rows; stamps[387] = n_steps; }
+        }
         if (failed) {
             out_status[blockIdx.x] = POA_ST_POOL;
             out_score[blockIdx.x] = POA_NEG;
@@ -436,7 +566,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
                 const uint32_t p = sink_preds[pb.sink0 + t];
                 const int bp = vbeg[p], ep = vend[p];
                 int val = POA_NEG;
-                if (qlen >= bp && qlen <= ep) val = ((const volatile int32_t *)(pool + vvoff[p]))[qlen - (bp & ~3)];
+                if (qlen >= bp && qlen <= ep) val = ((const int32_t *)(pool + vvoff[p]))[qlen - (bp & ~3)];
                 if (!have || val > bestv) { bestv = val; brow = p; have = true; }
             }
             out_score[blockIdx.x] = bestv;
@@ -486,13 +616,13 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
         if (nops + 1 >= cap) { bad = true; break; }
         if (src == 0) {
             const int t = np > 1 ? pool[doff + W + c] : 0;
-            const uint32_t p = first ? preds[pb.pred0 + inf.x + t] : i - 1;
+            const uint32_t p = first ? (np == 1 ? inf.x : preds[pb.pred0 + inf.x + t]) : i - 1;
             if (j < 1) { bad = true; break; }
             po[nops] = 0; pr[nops] = i; nops++;
             i = p; j -= 1; st = 0;
         } else if (src == 1 || src == 2) {
             const int t = np > 1 ? pool[doff + (src == 1 ? 2 : 3) * W + c] : 0;
-            const uint32_t p = first ? preds[pb.pred0 + inf.x + t] : i - 1;
+            const uint32_t p = first ? (np == 1 ? inf.x : preds[pb.pred0 + inf.x + t]) : i - 1;
             const int open = (code >> (src == 1 ? 6 : 7)) & 1;
             po[nops] = 2; pr[nops] = i; nops++;
             st = open ? 0 : src;
@@ -590,7 +720,8 @@ void poa_prepare(const poa_view &v, poa_prep &g)
             for (uint32_t t = in_off[i]; t < in_off[i + 1]; t++) g.preds.push_back(last_row[in_adj[t]]);
         }
         const uint32_t len = last_row[i] - g.first_row[i] + 1;
-        g.ntab[i + 1] = make_uint4(g.first_row[i], len | ((deg ? deg : 1u) << 24), (uint32_t)remain_last[i], pstart);
+        g.ntab[i + 1] = make_uint4(g.first_row[i], len | ((deg ? deg : 1u) << 24), (uint32_t)remain_last[i],
+                                   deg <= 1 ? g.preds[pstart] : pstart);
         if (out_off[i + 1] == out_off[i]) g.sinks.push_back(last_row[i]);
     }
     g.longest = longest;
@@ -670,8 +801,9 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     auto t_host0 = std::chrono::steady_clock::now();
     vga_trace tr("poa");
     if (params->gap_open1 < 0 || params->gap_open1 > 255 || params->gap_open2 < 0 || params->gap_open2 > 255 ||
-        params->gap_ext1 < 0 || params->gap_ext2 < 0)
-        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "gap open penalties must be in 0..255");
+        params->gap_ext1 < 0 || params->gap_ext2 < 0 || params->gap_open1 + params->gap_ext1 > 255 ||
+        params->gap_open2 + params->gap_ext2 > 255)
+        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "gap penalties: open + extend must be in 0..255 (one byte per gap state)");
     vga_timers_reset(ctx);
     if (n == 0) return VGA_OK;
 
@@ -768,10 +900,12 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         const char *env_pool = getenv("VGA_POOL_BYTES");
         if (env_pool) want = std::min<uint64_t>(want, strtoull(env_pool, nullptr, 10));
         if (W.pool_size < want) {
+            // grow generously (twice the estimated need) so that the adaptive scale does not trigger re-allocations:
+            // a hipMalloc of this size costs seconds
             size_t free_b = 0, total_b = 0;
             POA_CHECK(hipMemGetInfo(&free_b, &total_b));
             const uint64_t avail = (uint64_t)((double)(free_b + W.pool_size) * 0.85);
-            const uint64_t target = std::min(want, avail) & ~(POA_CHUNK - 1);
+            const uint64_t target = std::min(std::max<uint64_t>(2 * want, 8ull << 30), avail) & ~(POA_CHUNK - 1);
             if (target > W.pool_size) {
                 if (W.pool) { (void)hipFree(W.pool); W.pool = nullptr; W.pool_size = 0; }
                 if (target < 64 * POA_CHUNK)
@@ -832,6 +966,22 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             } else if (nt == 256) {
                 POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<256, 4>), dim3(nb), dim3(256), lds, st, POA_ARGS);
+            } else if (getenv("VGA_POA_STAMPS")) {
+                // diagnostic: per-segment cycle shares of the first 64 workgroups (tid 0's wave), printed to stderr
+                static unsigned long long *d_st = nullptr;
+                if (!d_st) POA_CHECK(hipMalloc((void **)&d_st, (64 * 6 + 4) * 8));
+                POA_CHECK(hipMemsetAsync(d_st, 0, (64 * 6 + 4) * 8, st));
+                POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<512, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_poa_dp_lds<512, 4, true>), dim3(nb), dim3(512), lds, st, POA_ARGS, d_st);
+                unsigned long long h_st[64 * 6 + 4];
+                POA_CHECK(hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, st));
+                POA_CHECK(hipStreamSynchronize(st));
+                unsigned long long sum[6] = {0, 0, 0, 0, 0, 0}, tot = 0;
+                for (int b2 = 0; b2 < 64 && b2 < (int)nb; b2++)
+                    for (int s = 0; s < 6; s++) { sum[s] += h_st[b2 * 6 + s]; tot += h_st[b2 * 6 + s]; }
+                fprintf(stderr, "[vga-stamps] cycles: prologue %llu phase1 %llu scans %llu step-barrier %llu phase2 %llu row-reduce+barrier %llu (total %llu)\n",
+                        sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], tot);
+                fprintf(stderr, "[vga-stamps] workgroup 0: rows %llu, far rows %llu, multi-predecessor rows %llu, steps %llu\n", h_st[386], h_st[384], h_st[385], h_st[387]);
             } else {
                 POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<512, 4>), dim3(nb), dim3(512), lds, st, POA_ARGS);
