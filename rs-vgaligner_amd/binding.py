@@ -291,15 +291,19 @@ class Batch:
                       poa_params: Optional[PoaParams] = None) -> dict:
         """One pass of the whole hot path without converting the results to numpy (bench.py's timed step).
         Returns counters only."""
+        import time as _t
         L = self.ctx.L
         mp = map_params or default_map_params()
         pp = poa_params or default_poa_params()
         m = _P(MapResult)()
+        t0 = _t.perf_counter()
         self.ctx._check(L.vga_map_batch(self.h, C.byref(mp), C.byref(m)))
+        t1 = _t.perf_counter()
         kt_map = self.ctx.kernel_times()
         try:
             a = _P(AlignResult)()
             self.ctx._check(L.vga_align_batch(self.h, m, best_n, C.byref(pp), C.byref(a)))
+            t2 = _t.perf_counter()
             kt_aln = self.ctx.kernel_times()
             r, q = a.contents, m.contents
             R = int(r.n_reads)
@@ -311,9 +315,14 @@ class Batch:
                        ms_map=float(q.ms_total), ms_probe=float(q.ms_probe), ms_sort=float(q.ms_sort), ms_chain=float(q.ms_chain),
                        ms_align=float(r.ms_total), ms_subgraph=float(r.ms_subgraph), ms_dp=float(r.ms_dp),
                        ms_traceback=float(r.ms_traceback), kernels=kt_map + kt_aln)
+            t3 = _t.perf_counter()
             L.vga_align_result_free(a)
         finally:
             L.vga_map_result_free(m)
+        t4 = _t.perf_counter()
+        out["ms_wall_map_call"] = (t1 - t0) * 1e3
+        out["ms_wall_align_call"] = (t2 - t1) * 1e3
+        out["ms_wall_free"] = (t4 - t3) * 1e3
         return out
 
     def close(self):

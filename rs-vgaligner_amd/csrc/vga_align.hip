@@ -225,10 +225,7 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
     // ---- subgraphs (host threads)
     std::vector<subgraph_t> SG(n);
     {
-        unsigned nt = std::thread::hardware_concurrency();
-        if (nt == 0) nt = 4;
-        if (nt > 32) nt = 32;
-        if ((uint64_t)nt > n) nt = (unsigned)std::max<uint64_t>(n, 1);
+        const unsigned nt = vga_host_threads(n);
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; t++)
             th.emplace_back([&, t]() {
@@ -274,7 +271,7 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
     res->cs_off = amalloc<uint64_t>(R + 1);
     std::vector<int64_t> pick(R, -1);
     std::vector<uint32_t> path_n(R, 0);
-    for (uint64_t r = 0; r < R; r++) {
+    vga_parallel_for(R, [&](uint64_t r) {
         int64_t best = -1;
         for (uint64_t p = read_prob0[r]; p < read_prob0[r + 1]; p++) {
             if (!items[p].ok) continue;
@@ -288,7 +285,7 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
             for (size_t t = 0; t < gn.size(); t++) c += (t == 0 || gn[t] != gn[t - 1]);
             path_n[r] = c;
         }
-    }
+    });
     uint64_t tp = 0, tc = 0, ts = 0;
     for (uint64_t r = 0; r < R; r++) {
         res->path_off[r] = tp; res->cigar_off[r] = tc; res->cs_off[r] = ts;
@@ -300,14 +297,14 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
     res->path_handles = amalloc<uint64_t>(tp);
     res->cigar = amalloc<char>(tc);
     res->cs = amalloc<char>(ts);
-    for (uint64_t r = 0; r < R; r++) {
+    vga_parallel_for(R, [&](uint64_t r) {
         res->aligned[r] = pick[r] >= 0;
         res->path_length[r] = res->path_start[r] = res->path_end[r] = res->block_length[r] = 0;
         res->best_score[r] = 0;
         if (pick[r] < 0) {
             res->cigar[res->cigar_off[r]] = 0;
             res->cs[res->cs_off[r]] = 0;
-            continue;
+            return;
         }
         const uint64_t p = (uint64_t)pick[r];
         const poa_item &it = items[p];
@@ -321,7 +318,7 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
         res->best_score[r] = it.score;
         memcpy(res->cigar + res->cigar_off[r], it.cigar.c_str(), it.cigar.size() + 1);
         memcpy(res->cs + res->cs_off[r], it.cs.c_str(), it.cs.size() + 1);
-    }
+    });
     res->poa_problems = n;
     for (uint64_t p = 0; p < n; p++) {
         res->poa_rows += items[p].n_rows; res->poa_cells += items[p].n_cells; res->poa_value_cells += items[p].n_vcells;

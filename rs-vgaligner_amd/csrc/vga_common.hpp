@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vga_hip.h"
@@ -113,6 +114,28 @@ struct vga_dbuf {
     ~vga_dbuf() { release(); }
 };
 
+// pinned, grow-only host staging buffer
+template <typename T>
+struct vga_hbuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    ~vga_hbuf()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+};
+
 // host-side phase tracing (VGA_TRACE=1): prints wall-clock deltas to stderr
 struct vga_trace {
     bool on;
@@ -127,6 +150,19 @@ struct vga_trace {
         t = n;
     }
 };
+
+// host thread fan-out (VGA_HOST_THREADS caps it; default: hardware concurrency, at most 32)
+unsigned vga_host_threads(uint64_t n);
+template <typename F>
+void vga_parallel_for(uint64_t n, F f)
+{
+    unsigned nt = vga_host_threads(n);
+    if (nt <= 1) { for (uint64_t i = 0; i < n; i++) f(i); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t]() { for (uint64_t i = t; i < n; i += nt) f(i); });
+    for (auto &x : th) x.join();
+}
 
 // event timing helpers (vga_ctx.hip)
 void vga_timers_reset(vga_ctx *ctx);

@@ -7,6 +7,8 @@
 // exact map gives the same answers, and 4^11 * 4 B = 16 MiB sits in the 256 MiB Infinity Cache.
 #include "vga_common.hpp"
 
+#include <malloc.h>
+
 int vga_set_error(vga_ctx *ctx, int code, const char *fmt, ...)
 {
     char buf[1024];
@@ -16,6 +18,17 @@ int vga_set_error(vga_ctx *ctx, int code, const char *fmt, ...)
     va_end(ap);
     if (ctx) ctx->err = buf;
     return code;
+}
+
+unsigned vga_host_threads(uint64_t n)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 32) nt = 32;
+    const char *e = getenv("VGA_HOST_THREADS");
+    if (e && atoi(e) > 0) nt = (unsigned)atoi(e);
+    if ((uint64_t)nt > n) nt = (unsigned)(n ? n : 1);
+    return nt;
 }
 
 extern "C" int vga_abi_version(void) { return VGA_ABI_VERSION; }
@@ -29,6 +42,18 @@ extern "C" int vga_ctx_create(int device, vga_ctx **out)
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0 || device < 0 || device >= n) return VGA_ERR_NO_DEVICE;
+    {
+        // Every call moves gigabytes of results through malloc'd arrays.  With glibc's defaults those come from
+        // mmap and go back to the kernel on free, so each call pays the page faults again (hundreds of ms per
+        // 10k-read batch).  Keep the memory in the heap instead.  VGA_KEEP_MALLOC_DEFAULTS=1 opts out.
+        static bool tuned = false;
+        if (!tuned && !getenv("VGA_KEEP_MALLOC_DEFAULTS")) {
+            mallopt(M_MMAP_THRESHOLD, 1 << 30);
+            mallopt(M_TRIM_THRESHOLD, INT32_MAX);
+            mallopt(M_TOP_PAD, 256 << 20);
+            tuned = true;
+        }
+    }
     vga_ctx *ctx = new vga_ctx();
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return VGA_ERR_NO_DEVICE; }

@@ -335,6 +335,10 @@ struct map_ws {
     vga_dbuf<double> f, curr_max, gap_cost;
     vga_dbuf<int32_t> pred_id, pred_pos;
     vga_dbuf<uint32_t> chain_buf, chain_cnt, chain_words, key_a;
+    // pinned staging for the result copies (pageable D2H runs at a fraction of the PCIe rate)
+    vga_hbuf<uint32_t> h_id, h_qb, h_tb, h_te, h_chain_buf, h_chain_cnt, h_chain_words, h_cnt;
+    vga_hbuf<double> h_f, h_curr_max;
+    vga_hbuf<int32_t> h_pred;
 };
 
 template <typename T>
@@ -421,8 +425,9 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
                        ix.d_table, ix.d_pos, ws.cnt.p, (const uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                        (uint32_t *)nullptr, (uint32_t *)nullptr);
     vga_timer_end(ctx, t1);
-    std::vector<uint32_t> h_cnt(R);
-    MAP_CHECK(hipMemcpyAsync(h_cnt.data(), ws.cnt.p, R * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    MAP_CHECK(ws.h_cnt.reserve(R));
+    uint32_t *h_cnt = ws.h_cnt.p;
+    MAP_CHECK(hipMemcpyAsync(h_cnt, ws.cnt.p, R * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MAP_CHECK(hipStreamSynchronize(st));
     tr.mark("count kernel + sync");
     uint64_t total = 0;
@@ -490,30 +495,50 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     vga_timer_end(ctx, t_total);
 
     tr.mark("launches");
-    // ---- results to host
+    // ---- results to host: async copies into pinned staging, then a threaded fan-out into the result arrays
+    MAP_CHECK(ws.h_id.reserve(An)); MAP_CHECK(ws.h_qb.reserve(An)); MAP_CHECK(ws.h_tb.reserve(An)); MAP_CHECK(ws.h_te.reserve(An));
+    MAP_CHECK(ws.h_f.reserve(An)); MAP_CHECK(ws.h_pred.reserve(An)); MAP_CHECK(ws.h_chain_buf.reserve(3 * An + 2 * R + 2));
+    MAP_CHECK(ws.h_curr_max.reserve(R)); MAP_CHECK(ws.h_chain_cnt.reserve(R)); MAP_CHECK(ws.h_chain_words.reserve(R));
+    if (An) {
+        MAP_CHECK(hipMemcpyAsync(ws.h_id.p, perm, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(ws.h_qb.p, ws.s_qb.p, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(ws.h_tb.p, ws.s_tb.p, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(ws.h_te.p, ws.s_te.p, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(ws.h_f.p, ws.f.p, An * 8, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(ws.h_pred.p, ws.pred_id.p, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(ws.h_chain_buf.p, ws.chain_buf.p, (3 * An + 2 * R) * 4, hipMemcpyDeviceToHost, st));
+    }
+    MAP_CHECK(hipMemcpyAsync(ws.h_curr_max.p, ws.curr_max.p, R * 8, hipMemcpyDeviceToHost, st));
+    MAP_CHECK(hipMemcpyAsync(ws.h_chain_cnt.p, ws.chain_cnt.p, R * 4, hipMemcpyDeviceToHost, st));
+    MAP_CHECK(hipMemcpyAsync(ws.h_chain_words.p, ws.chain_words.p, R * 4, hipMemcpyDeviceToHost, st));
     res->anchor_id = xmalloc<uint32_t>(An);
     res->query_begin = xmalloc<uint32_t>(An);
     res->target_begin = xmalloc<uint32_t>(An);
     res->target_end = xmalloc<uint32_t>(An);
     res->max_chain_score = xmalloc<double>(An);
     res->best_pred_id = xmalloc<int32_t>(An);
-    std::vector<uint32_t> h_chain_cnt(R), h_chain_words(R);
-    std::vector<uint32_t> h_chain_buf(3 * An + 2 * R + 2);
-    if (An) {
-        MAP_CHECK(hipMemcpyAsync(res->anchor_id, perm, An * 4, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(res->query_begin, ws.s_qb.p, An * 4, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(res->target_begin, ws.s_tb.p, An * 4, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(res->target_end, ws.s_te.p, An * 4, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(res->max_chain_score, ws.f.p, An * 8, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(res->best_pred_id, ws.pred_id.p, An * 4, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(h_chain_buf.data(), ws.chain_buf.p, (3 * An + 2 * R) * 4, hipMemcpyDeviceToHost, st));
-    }
-    MAP_CHECK(hipMemcpyAsync(res->curr_max, ws.curr_max.p, R * 8, hipMemcpyDeviceToHost, st));
-    MAP_CHECK(hipMemcpyAsync(h_chain_cnt.data(), ws.chain_cnt.p, R * 4, hipMemcpyDeviceToHost, st));
-    MAP_CHECK(hipMemcpyAsync(h_chain_words.data(), ws.chain_words.p, R * 4, hipMemcpyDeviceToHost, st));
     MAP_CHECK(hipStreamSynchronize(st));
     tr.mark("kernels + D2H");
     vga_timers_collect(ctx);
+    {
+        const uint64_t NCH = 64;  // chunks per array
+        vga_parallel_for(6 * NCH, [&](uint64_t job) {
+            const uint64_t arr = job / NCH, ch = job % NCH;
+            const uint64_t lo = An * ch / NCH, hi = An * (ch + 1) / NCH;
+            if (hi <= lo) return;
+            switch (arr) {
+            case 0: memcpy(res->anchor_id + lo, ws.h_id.p + lo, (hi - lo) * 4); break;
+            case 1: memcpy(res->query_begin + lo, ws.h_qb.p + lo, (hi - lo) * 4); break;
+            case 2: memcpy(res->target_begin + lo, ws.h_tb.p + lo, (hi - lo) * 4); break;
+            case 3: memcpy(res->target_end + lo, ws.h_te.p + lo, (hi - lo) * 4); break;
+            case 4: memcpy(res->max_chain_score + lo, ws.h_f.p + lo, (hi - lo) * 8); break;
+            default: memcpy(res->best_pred_id + lo, ws.h_pred.p + lo, (hi - lo) * 4); break;
+            }
+        });
+        memcpy(res->curr_max, ws.h_curr_max.p, R * 8);
+    }
+    const uint32_t *h_chain_cnt = ws.h_chain_cnt.p, *h_chain_words = ws.h_chain_words.p, *h_chain_buf = ws.h_chain_buf.p;
+    tr.mark("fan-out to result arrays");
 
     // ---- chains: discovery order per read, members reversed to ascending (src/chain.rs:546);
     // a read without chains gets one placeholder (src/chain.rs:644-649)
@@ -530,7 +555,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     uint64_t ci = 0, mi = 0;
     for (uint64_t r = 0; r < R; r++) {
         res->chain_off[r] = ci;
-        const uint32_t *buf = h_chain_buf.data() + 3 * res->anchor_off[r] + 2 * r;
+        const uint32_t *buf = h_chain_buf + 3 * res->anchor_off[r] + 2 * r;
         uint32_t c = h_chain_cnt[r], wp = 0;
         if (c == 0) {
             res->chain_placeholder[ci] = 1;

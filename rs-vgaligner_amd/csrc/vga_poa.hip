@@ -768,25 +768,8 @@ void append_u(std::string &s, uint64_t v)
 
 inline char lower(char c) { return (c >= 'A' && c <= 'Z') ? (char)(c + 32) : c; }
 
-unsigned host_threads(uint64_t n)
-{
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 4;
-    if (nt > 32) nt = 32;
-    if ((uint64_t)nt > n) nt = (unsigned)std::max<uint64_t>(n, 1);
-    return nt;
-}
-
 template <typename F>
-void parallel_for(uint64_t n, F f)
-{
-    unsigned nt = host_threads(n);
-    if (nt <= 1) { for (uint64_t i = 0; i < n; i++) f(i); return; }
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([&, t]() { for (uint64_t i = t; i < n; i += nt) f(i); });
-    for (auto &x : th) x.join();
-}
+void parallel_for(uint64_t n, F f) { vga_parallel_for(n, f); }
 
 }  // namespace
 
@@ -892,6 +875,11 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     std::vector<uint32_t> order(n);
     for (uint64_t p = 0; p < n; p++) { est[p] = est_bytes(p); order[p] = (uint32_t)p; }
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return est[a] > est[b]; });
+    {
+        // the traceback output of a sub-batch must be one contiguous slice: number it in launch order
+        uint64_t o = 0;
+        for (uint64_t i = 0; i < n; i++) { probs[order[i]].ops0 = o; o += (uint64_t)G[order[i]].N + G[order[i]].qlen + 2; }
+    }
     for (uint64_t i = 0; i < n; i++) W.h_probs.p[i] = probs[order[i]];
     {
         double want_d = 0;
@@ -928,9 +916,10 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     P.o2 = params->gap_open2; P.e2 = params->gap_ext2; P.banded = params->wb >= 0;
 
     int t_total = vga_timer_begin(ctx, "poa_total", 0);
-    uint64_t i0 = 0;
-    int rc_final = VGA_OK;
-    while (i0 < n) {
+    struct sub_t { uint64_t i0, i1; double raw_est; };
+    hipError_t launch_err = hipSuccess;
+    // enqueue DP + traceback + result copies of the sub-batch starting at launch position i0
+    auto launch = [&](uint64_t i0) -> sub_t {
         const double budget = (double)W.pool_size * 0.92;
         double used_est = 0, raw_est = 0;
         uint64_t i1 = i0;
@@ -942,7 +931,8 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             i1++;
         }
         const uint32_t nb = (uint32_t)(i1 - i0);
-        POA_CHECK(hipMemsetAsync(W.d_next.p, 0, sizeof(unsigned long long), st));
+        auto chk = [&](hipError_t e) { if (e != hipSuccess && launch_err == hipSuccess) launch_err = e; };
+        chk(hipMemsetAsync(W.d_next.p, 0, sizeof(unsigned long long), st));
         int t_dp = vga_timer_begin(ctx, "poa_band_dp", 0);
         {
             uint32_t mq = 0;
@@ -961,21 +951,21 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
                  W.d_voff.p, W.d_lmax.p, W.d_rmax.p, W.d_info.p, W.pool, W.d_next.p, W.pool_size, W.d_score.p + i0, W.d_row.p + i0, \
                  W.d_status.p + i0, W.d_cells.p + i0, W.d_vcells.p + i0, lds_cols
             if (nt == 128) {
-                POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<128, 4>), dim3(nb), dim3(128), lds, st, POA_ARGS);
             } else if (nt == 256) {
-                POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<256, 4>), dim3(nb), dim3(256), lds, st, POA_ARGS);
             } else if (getenv("VGA_POA_STAMPS")) {
                 // diagnostic: per-segment cycle shares of the first 64 workgroups (tid 0's wave), printed to stderr
                 static unsigned long long *d_st = nullptr;
-                if (!d_st) POA_CHECK(hipMalloc((void **)&d_st, (64 * 6 + 4) * 8));
-                POA_CHECK(hipMemsetAsync(d_st, 0, (64 * 6 + 4) * 8, st));
-                POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<512, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (!d_st) chk(hipMalloc((void **)&d_st, (64 * 6 + 4) * 8));
+                chk(hipMemsetAsync(d_st, 0, (64 * 6 + 4) * 8, st));
+                chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<512, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<512, 4, true>), dim3(nb), dim3(512), lds, st, POA_ARGS, d_st);
                 unsigned long long h_st[64 * 6 + 4];
-                POA_CHECK(hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, st));
-                POA_CHECK(hipStreamSynchronize(st));
+                chk(hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, st));
+                chk(hipStreamSynchronize(st));
                 unsigned long long sum[6] = {0, 0, 0, 0, 0, 0}, tot = 0;
                 for (int b2 = 0; b2 < 64 && b2 < (int)nb; b2++)
                     for (int s = 0; s < 6; s++) { sum[s] += h_st[b2 * 6 + s]; tot += h_st[b2 * 6 + s]; }
@@ -983,11 +973,11 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
                         sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], tot);
                 fprintf(stderr, "[vga-stamps] workgroup 0: rows %llu, far rows %llu, multi-predecessor rows %llu, steps %llu\n", h_st[386], h_st[384], h_st[385], h_st[387]);
             } else {
-                POA_CHECK(hipFuncSetAttribute((const void *)k_poa_dp_lds<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<512, 4>), dim3(nb), dim3(512), lds, st, POA_ARGS);
             }
 #undef POA_ARGS
-            POA_CHECK(hipGetLastError());
+            chk(hipGetLastError());
         }
         vga_timer_end(ctx, t_dp);
         int t_tb = vga_timer_begin(ctx, "poa_traceback", 0);
@@ -995,41 +985,20 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
                            W.d_beg.p, W.d_end.p, W.d_doff.p, W.pool, W.d_row.p + i0, W.d_status.p + i0, W.d_ops.p, W.d_orow.p,
                            W.d_nops.p + i0);
         vga_timer_end(ctx, t_tb);
-        POA_CHECK(hipMemcpyAsync(W.h_status.p + i0, W.d_status.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
-        POA_CHECK(hipMemcpyAsync(W.h_next.p, W.d_next.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        POA_CHECK(hipStreamSynchronize(st));
-        bool pool_fail = false;
-        for (uint64_t i = i0; i < i1; i++)
-            if (W.h_status.p[i] == POA_ST_POOL) pool_fail = true;
-        if (pool_fail) {
-            if (nb == 1 && W.pool_scale >= 4.0) { rc_final = VGA_ERR_POOL; break; }
-            W.pool_scale = std::min(8.0, W.pool_scale * 1.7);
-            continue;  // rerun this sub-batch with a more cautious estimate
-        }
-        if (raw_est > 0) {
-            const double ratio = (double)W.h_next.p[0] / raw_est;
-            W.pool_scale = std::max(ratio * 1.15, 0.6 * W.pool_scale + 0.4 * ratio * 1.25);
-        }
-        i0 = i1;
-    }
-    vga_timer_end(ctx, t_total);
-    tr.mark("dp + traceback (sub-batches)");
-    if (rc_final != VGA_OK)
-        return vga_set_error(ctx, rc_final, "a single POA problem does not fit the %llu byte traceback pool",
-                             (unsigned long long)W.pool_size);
-    POA_CHECK(hipMemcpyAsync(W.h_score.p, W.d_score.p, n * 4, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(W.h_row.p, W.d_row.p, n * 4, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(W.h_nops.p, W.d_nops.p, n * 4, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(W.h_cells.p, W.d_cells.p, n * 8, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(W.h_vcells.p, W.d_vcells.p, n * 8, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(W.h_ops.p, W.d_ops.p, tot_ops, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipMemcpyAsync(W.h_orow.p, W.d_orow.p, tot_ops * 4, hipMemcpyDeviceToHost, st));
-    POA_CHECK(hipStreamSynchronize(st));
-    tr.mark("D2H ops");
-    vga_timers_collect(ctx);
-
-    // ---- host: CIGAR / cs / node path from the raw op stream (reverse order on the device)
-    parallel_for(n, [&](uint64_t i) {
+        const uint64_t o0 = probs[order[i0]].ops0;
+        const uint64_t o1 = i1 < n ? probs[order[i1]].ops0 : tot_ops;
+        chk(hipMemcpyAsync(W.h_status.p + i0, W.d_status.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(W.h_next.p, W.d_next.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(W.h_score.p + i0, W.d_score.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(W.h_nops.p + i0, W.d_nops.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(W.h_cells.p + i0, W.d_cells.p + i0, nb * 8, hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(W.h_vcells.p + i0, W.d_vcells.p + i0, nb * 8, hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(W.h_ops.p + o0, W.d_ops.p + o0, o1 - o0, hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(W.h_orow.p + o0, W.d_orow.p + o0, (o1 - o0) * 4, hipMemcpyDeviceToHost, st));
+        return {i0, i1, raw_est};
+    };
+    // host: CIGAR / cs / node path of one problem from the raw op stream (reverse order on the device)
+    auto post_one = [&](uint64_t i) {
         const uint32_t p = order[i];
         poa_item &it = out[p];
         it.ok = W.h_status.p[i] == POA_ST_OK ? 1 : 0;
@@ -1095,8 +1064,45 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             it.start_off = it.rows.front() - g.first_row[it.gnodes.front()];
             it.end_off = it.rows.back() - g.first_row[it.gnodes.back()] + 1;
         }
-    });
-    tr.mark("cigar/cs (host threads)");
+    };
+    // Software pipeline: while the GPU runs sub-batch i+1 the host threads turn sub-batch i's op streams into
+    // CIGAR / cs strings.
+    int rc_final = VGA_OK;
+    sub_t cur = launch(0);
+    while (true) {
+        POA_CHECK(hipStreamSynchronize(st));
+        if (launch_err != hipSuccess)
+            return vga_set_error(ctx, VGA_ERR_HIP, "POA launch failed: %s", hipGetErrorString(launch_err));
+        bool pool_fail = false;
+        for (uint64_t i = cur.i0; i < cur.i1; i++)
+            if (W.h_status.p[i] == POA_ST_POOL) pool_fail = true;
+        if (pool_fail) {
+            if (cur.i1 - cur.i0 == 1 && W.pool_scale >= 4.0) { rc_final = VGA_ERR_POOL; break; }
+            W.pool_scale = std::min(8.0, W.pool_scale * 1.7);
+            cur = launch(cur.i0);  // rerun this sub-batch with a more cautious estimate
+            continue;
+        }
+        if (cur.raw_est > 0) {
+            const double ratio = (double)W.h_next.p[0] / cur.raw_est;
+            W.pool_scale = std::max(ratio * 1.15, 0.6 * W.pool_scale + 0.4 * ratio * 1.25);
+        }
+        const bool have_next = cur.i1 < n;
+        sub_t nxt = cur;
+        if (have_next) nxt = launch(cur.i1);
+        {
+            const uint64_t a0 = cur.i0, cnt = cur.i1 - cur.i0;
+            parallel_for(cnt, [&](uint64_t t) { post_one(a0 + t); });
+        }
+        if (!have_next) break;
+        cur = nxt;
+    }
+    vga_timer_end(ctx, t_total);
+    tr.mark("dp + traceback + cigar (pipelined sub-batches)");
+    if (rc_final != VGA_OK)
+        return vga_set_error(ctx, rc_final, "a single POA problem does not fit the %llu byte traceback pool",
+                             (unsigned long long)W.pool_size);
+    POA_CHECK(hipStreamSynchronize(st));
+    vga_timers_collect(ctx);
     // byte model of the DP kernel: graph bases + query + 1 direction byte per cell
     // + the 6-byte value rows of node-end bases, written once and read back at least once
     uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;

@@ -37,24 +37,3 @@ struct poa_timing {
 int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_params *params, std::vector<poa_item> &out,
             poa_timing &tm);
 
-// pinned, grow-only host staging buffer
-template <typename T>
-struct vga_hbuf {
-    T *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t n)
-    {
-        if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = n + n / 8 + 64;
-        hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    ~vga_hbuf()
-    {
-        if (p) (void)hipHostFree(p);
-    }
-};
