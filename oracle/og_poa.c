@@ -35,7 +35,7 @@
  */
 #include "og_internal.h"
 
-#define OG_NEG (-(1 << 29))
+#define OG_NEG (-(1 << 21)) /* "minus infinity": far below any real score of a read up to ~100 kbp, small enough that the GPU kernel keeps H in 23 signed bits */
 
 void og_poa_default_params(og_poa_params *p)
 {

@@ -30,7 +30,7 @@
 #include <chrono>
 #include <thread>
 
-#define POA_NEG (-(1 << 29))
+#define POA_NEG (-(1 << 21))  // "minus infinity"; H stays inside 23 signed bits (see k_poa_dp_pk)
 #define POA_IDENT (INT32_MIN / 2)
 #define POA_CHUNK (1ull << 20)
 
@@ -644,6 +644,470 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
     out_nops[pi] = (uint32_t)nops;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K4, packed form (the default).  Same algorithm and outputs as k_poa_dp_lds; the differences are about
+// residency:
+//   * one 32-bit LDS word per column:  (H << 8) | g1 | g2 << G1B   with gk = Ek + min(H - E_k, Ok) (G1B + G2B <= 8
+//     bits for the usual penalties; H needs 23 signed bits), and the query as 4-bit codes indexed by COLUMN
+//     (nibble j = code of query[j-1]).  4.5 B per column instead of 7 => 45 KB at 10 kbp => three workgroups per CU;
+//   * between the two phases of a step a cell is carried as  ht  plus one packed word (source of Ht, open flags,
+//     u_k = min(Ht - E_k, O_k)); the open/extend deltas of H are rebuilt from u_k in phase 2
+//     (min(H - E_k, O_k) = min(u_k + (H - Ht), O_k) because H >= Ht), so the kernel fits 80 VGPRs = 6 waves/SIMD;
+//   * node-end value rows in HBM are the same packed words (4 B per cell);
+//   * single-predecessor rows whose predecessor is not the row above ("far") use the lean path as well, with
+//     their five words coming from HBM instead of LDS.
+template <int NT, bool STAMP = false>
+__global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
+    const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
+    const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
+    poa_dev_params P, int32_t *row_beg, int32_t *row_end, uint64_t *row_doff, uint64_t *row_voff, int32_t *row_lmax,
+    int32_t *row_rmax, uint2 *row_info, uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size,
+    int32_t *__restrict__ out_score, uint32_t *__restrict__ out_row, int32_t *__restrict__ out_status,
+    uint64_t *__restrict__ out_cells, uint64_t *__restrict__ out_vcells, uint32_t lds_cols, int g1bits,
+    unsigned long long *stamps = nullptr)
+{
+    constexpr int CPT = 4;
+    constexpr int NW = NT / 64;
+    constexpr int STEP = NT * CPT;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int32_t *HG = (int32_t *)smem;                               // [lds_cols] (H << 8) | g
+    uint16_t *Qn = (uint16_t *)(smem + 4ull * lds_cols);         // [lds_cols / 4] four column codes per halfword
+    int32_t *scr = (int32_t *)(smem + 4ull * lds_cols + lds_cols / 2);  // lds_cols is a multiple of 16
+    int32_t *sW1 = scr;               // [2][NW]
+    int32_t *sW2 = sW1 + 2 * NW;
+    int32_t *sL1 = sW2 + 2 * NW;
+    int32_t *sL2 = sL1 + 2 * NW;
+    int32_t *sRed = sL2 + 2 * NW;     // [NW][3]
+    int32_t *edgeW = sRed + 3 * NW;   // [2]
+    unsigned long long *s_alloc = (unsigned long long *)(edgeW + 2);
+
+    const poa_prob pb = probs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int qlen = (int)pb.qlen;
+    const char *query = queries + pb.q0;
+    const uint4 *ntab = node_tab + pb.node0;
+    const uint32_t *plist = preds + pb.pred0;
+    int32_t *vbeg = row_beg + pb.row0;
+    int32_t *vend = row_end + pb.row0;
+    uint64_t *vvoff = row_voff + pb.row0;
+    int32_t *vlmax = row_lmax + pb.row0;
+    int32_t *vrmax = row_rmax + pb.row0;
+    uint64_t *gdoff = row_doff + pb.row0;
+    uint2 *ginfo = row_info + pb.row0;
+
+    const int o1 = P.o1, e1 = P.e1, o2 = P.o2, e2 = P.e2;
+    const int oe1 = o1 + e1, oe2 = o2 + e2;
+    const int g1mask = (1 << g1bits) - 1;
+    const int bw = (int)pb.w;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int seg) {
+        if constexpr (STAMP) {
+            unsigned long long t;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            if (seg >= 0) tacc[seg] += t - tprev;
+            tprev = t;
+        }
+    };
+
+    uint64_t dcur = 0, dend = 0, vcur = 0, vendp = 0;
+    bool failed = false;
+    auto take_chunk = [&](uint64_t &cur, uint64_t &end) {
+        __syncthreads();
+        if (tid == 0) *s_alloc = atomicAdd(pool_next, (unsigned long long)POA_CHUNK);
+        __syncthreads();
+        uint64_t b = *s_alloc;
+        if (b + POA_CHUNK > pool_size) failed = true;
+        cur = b;
+        end = b + POA_CHUNK;
+    };
+    auto alloc = [&](uint64_t &cur, uint64_t &end, uint64_t bytes) -> uint64_t {
+        bytes = (bytes + 15ull) & ~15ull;
+        if (cur + bytes > end) take_chunk(cur, end);
+        uint64_t r = cur;
+        cur += bytes;
+        return r;
+    };
+
+    // column codes: nibble j = code of query[j-1] (0..3 = ACGT, 4 = anything else incl. column 0)
+    for (int t = tid; t < (int)(lds_cols / 4); t += NT) {
+        uint32_t hw = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = 4 * t + k;
+            uint32_t code = 4;
+            if (j >= 1 && j <= qlen) {
+                const char ch = query[j - 1];
+                code = ch == 'A' ? 0u : (ch == 'C' ? 1u : (ch == 'G' ? 2u : (ch == 'T' ? 3u : 4u)));
+            }
+            hw |= code << (4 * k);
+        }
+        Qn[t] = (uint16_t)hw;
+    }
+    __syncthreads();
+
+    int prev_beg = 0, prev_end = -1, prev_lmax = 0, prev_rmax = 0;
+    uint64_t cells = 0, vcells = 0;
+    uint32_t seq_word = 0, seq_word_idx = 0xFFFFFFFFu;
+
+    for (uint32_t v = 0; v < pb.n_nodes && !failed; v++) {
+    const uint4 nt = ntab[v];
+    const uint32_t nlen = nt.y & 0xFFFFFFu;
+    for (uint32_t tn = 0; tn < nlen && !failed; tn++) {
+        const uint32_t r = nt.x + tn;
+        const bool first = tn == 0 && v > 0;
+        const bool last = tn + 1 == nlen;
+        const int np = v == 0 ? 0 : (tn == 0 ? (int)(nt.y >> 24) : 1);
+        const uint32_t ps = nt.w;
+        const int remain = (int)nt.z + (int)(nlen - 1 - tn);
+        uint8_t gb = 0;
+        if (v > 0) {
+            const uint32_t bi = r - 1;
+            if ((bi & 3u) == 0 || (bi >> 2) != seq_word_idx) { seq_word_idx = bi >> 2; seq_word = seq32[(pb.seq0 >> 2) + seq_word_idx]; }
+            gb = (uint8_t)(seq_word >> (8u * (bi & 3u)));
+        }
+        stamp(-1);
+        bool far = false;
+        if (first) {
+            if (np == 1) far = ps != r - 1;
+            else
+                for (int t = 0; t < np; t++) far |= plist[ps + t] != r - 1;
+        }
+        if (far) __syncthreads();  // vmcnt(0) + barrier: the value rows / row arrays of far predecessors have landed
+        int mpl, mpr;
+        if (r == 0) { mpl = 0; mpr = 0; }
+        else if (!first) { mpl = prev_lmax + 1; mpr = prev_rmax + 1; }
+        else {
+            mpl = INT32_MAX; mpr = 0;
+            for (int t = 0; t < np; t++) {
+                const uint32_t p = np == 1 ? ps : plist[ps + t];
+                int lm, rm;
+                if (p == r - 1) { lm = prev_lmax + 1; rm = prev_rmax + 1; }
+                else { lm = vlmax[p] + 1; rm = vrmax[p] + 1; }
+                mpl = lm < mpl ? lm : mpl;
+                mpr = rm > mpr ? rm : mpr;
+            }
+        }
+        int beg, end;
+        if (!P.banded) { beg = 0; end = qlen; }
+        else {
+            const int diag = qlen - remain;
+            const int lo = mpl < diag ? mpl : diag;
+            const int hi = mpr > diag ? mpr : diag;
+            beg = lo - bw; if (beg < 0) beg = 0;
+            end = hi + bw; if (end > qlen) end = qlen;
+        }
+        const int bal = beg & ~3;
+        const int W = (end - bal + 1 + 3) & ~3;  // storage width / plane stride
+        if (r > 0) cells += (uint64_t)(end - beg + 1);
+        if (last) vcells += (uint64_t)(end - beg + 1);
+        const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u));
+        if (failed) break;
+        uint64_t voff = 0;
+        if (last) { voff = alloc(vcur, vendp, 4ull * (uint64_t)W); if (failed) break; }
+        if (tid == 0) {
+            vbeg[r] = beg;
+            vend[r] = end;
+            gdoff[r] = doff;
+            vvoff[r] = voff;
+            ginfo[r] = make_uint2(ps, first ? (uint32_t)np : 0u);
+        }
+        int32_t *Vrow = (int32_t *)(pool + voff);  // value row: packed words
+        uint8_t *drow = pool + doff;
+        const int gcode = gb == 'A' ? 0 : (gb == 'C' ? 1 : (gb == 'G' ? 2 : (gb == 'T' ? 3 : 4)));
+        const int sc_eq = gcode == 4 ? 0 : P.match, sc_ne = gcode == 4 ? 0 : -P.mismatch;
+        // one predecessor (the row above in LDS, or a far row in HBM): the branch-free lean path applies
+        const bool single = r > 0 && np == 1;
+        const uint32_t sp = first ? ps : r - 1;  // that predecessor
+        const bool sp_near = sp == r - 1;
+        int pbeg = prev_beg, pend = prev_end;
+        const int32_t *Vp = nullptr;
+        int balp = 0;
+        if (single && !sp_near) {
+            pbeg = vbeg[sp]; pend = vend[sp];
+            Vp = (const int32_t *)(pool + vvoff[sp]);
+            balp = pbeg & ~3;
+        }
+        stamp(0);
+
+        int carry1 = POA_IDENT, carry2 = POA_IDENT, left1 = POA_IDENT, left2 = POA_IDENT;
+        int best = INT32_MIN, lpos = beg, rpos = beg;
+        int buf = 0;
+        const unsigned span = (unsigned)(end - beg);
+        for (int c0 = 0; c0 < W; c0 += STEP, buf ^= 1) {
+            const int c = c0 + CPT * tid;
+            const int j0 = bal + c;
+            const bool lane_act = j0 <= end;
+            const int nw_step = (W - c0 + 64 * CPT - 1) / (64 * CPT) < NW ? (W - c0 + 64 * CPT - 1) / (64 * CPT) : NW;
+            const bool wave_act = wv < nw_step;
+            // carried from phase 1 to phase 2, per cell: ht and  meta = hts | ofl << 2 | u1 << 8 | u2 << 16
+            int ht[CPT], meta[CPT], pmeta[CPT];
+            int agg1 = POA_IDENT, agg2 = POA_IDENT, alast1 = POA_IDENT, alast2 = POA_IDENT;
+            int wold[CPT];  // this lane's LDS words (their low byte is rewritten together with H)
+#pragma unroll
+            for (int k = 0; k < CPT; k++) { ht[k] = POA_NEG; meta[k] = (o1 << 8) | (o2 << 16); pmeta[k] = 0; wold[k] = 0; }
+            const uint32_t qn = wave_act ? (uint32_t)Qn[j0 >> 2] : 0x4444u;
+            if (wave_act && single) {
+                // ---------------- lean path, phase 1
+                int wj[CPT], wm0;
+                const unsigned pspan = (unsigned)(pend - pbeg);
+                if (sp_near) {
+                    const int4 hv = *(const int4 *)(HG + j0);
+                    wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
+                    if (tid == NT - 1) edgeW[buf] = hv.w;
+                    const int jm1 = j0 > 0 ? j0 - 1 : 0;
+                    wm0 = (tid == 0 && c0 > 0) ? edgeW[buf ^ 1] : HG[jm1];
+                } else {
+                    const int idx = j0 - balp;
+                    const int Wp = (pend - balp + 1 + 3) & ~3;
+                    int4 hv = make_int4(0, 0, 0, 0);
+                    if (idx >= 0 && idx < Wp) hv = *(const int4 *)(Vp + idx);
+                    wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
+                    wm0 = (idx >= 1 && idx - 1 < Wp) ? Vp[idx - 1] : 0;
+                    // keep the in-place protocol of the LDS row intact for the next (near) row
+                }
+                bool inprev = j0 >= 1 && (unsigned)(j0 - 1 - pbeg) <= pspan;
+#pragma unroll
+                for (int k = 0; k < CPT; k++) {
+                    const int j = j0 + k;
+                    const bool inj = (unsigned)(j - pbeg) <= pspan;
+                    const bool actk = (unsigned)(j - beg) <= span;
+                    const int qc = (int)((qn >> (4 * k)) & 15u);
+                    const int s = qc == gcode ? sc_eq : (qc == 4 ? 0 : sc_ne);
+                    const int wm = k == 0 ? wm0 : wj[k - 1];
+                    const int hj = wj[k] >> 8, g = wj[k] & 255;
+                    const int g1 = g & g1mask, g2 = g >> g1bits;
+                    const int m = inprev ? (wm >> 8) + s : POA_NEG;
+                    const int ev1 = inj ? hj - g1 : POA_NEG;
+                    const int ev2 = inj ? hj - g2 : POA_NEG;
+                    const int me = m > ev1 ? m : ev1;
+                    const int h = me > ev2 ? me : ev2;
+                    const int hts = ev2 > me ? 2 : (ev1 > m ? 1 : 0);
+                    const int ofl = (g1 == oe1 ? 1 : 0) | (g2 == oe2 ? 2 : 0);
+                    int u1 = h - ev1; u1 = u1 < o1 ? u1 : o1;
+                    int u2 = h - ev2; u2 = u2 < o2 ? u2 : o2;
+                    ht[k] = h;
+                    meta[k] = hts | (ofl << 2) | (u1 << 8) | (u2 << 16);
+                    const int a1 = actk ? h + e1 * j : POA_IDENT, a2 = actk ? h + e2 * j : POA_IDENT;
+                    agg1 = a1 > agg1 ? a1 : agg1;
+                    agg2 = a2 > agg2 ? a2 : agg2;
+                    if (k == CPT - 1) { alast1 = a1; alast2 = a2; }
+                    inprev = inj;
+                }
+            } else if (wave_act) {
+                // ---------------- general path, phase 1: the source row and rows with several predecessors
+                if (r == 0) {
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) ht[k] = (j0 + k == 0) ? 0 : POA_NEG;
+                } else if (lane_act) {
+                    int m[CPT], ev1[CPT], ev2[CPT], hts[CPT], ofl[CPT];
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) { m[k] = POA_NEG; ev1[k] = POA_NEG; ev2[k] = POA_NEG; hts[k] = 0; ofl[k] = 0; }
+                    for (int t = 0; t < np; t++) {
+                        const uint32_t p = plist[ps + t];
+                        int wj[CPT], wm0 = 0;
+                        int bp, ep;
+                        if (p == r - 1) {
+                            bp = prev_beg; ep = prev_end;
+                            const int4 hv = *(const int4 *)(HG + j0);
+                            wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
+                            if (tid == NT - 1) edgeW[buf] = hv.w;
+                            const int jm1 = j0 > 0 ? j0 - 1 : 0;
+                            wm0 = (tid == 0 && c0 > 0) ? edgeW[buf ^ 1] : HG[jm1];
+                        } else {
+                            bp = vbeg[p]; ep = vend[p];
+                            const int32_t *Vq = (const int32_t *)(pool + vvoff[p]);
+                            const int balq = bp & ~3;
+                            const int Wq = (ep - balq + 1 + 3) & ~3;
+                            const int idx = j0 - balq;
+                            int4 hv = make_int4(0, 0, 0, 0);
+                            if (idx >= 0 && idx < Wq) hv = *(const int4 *)(Vq + idx);
+                            wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
+                            wm0 = (idx >= 1 && idx - 1 < Wq) ? Vq[idx - 1] : 0;
+                        }
+                        const unsigned pspan = (unsigned)(ep - bp);
+#pragma unroll
+                        for (int k = 0; k < CPT; k++) {
+                            const int j = j0 + k;
+                            const bool actk = (unsigned)(j - beg) <= span;
+                            const int qc = (int)((qn >> (4 * k)) & 15u);
+                            const int s = qc == gcode ? sc_eq : (qc == 4 ? 0 : sc_ne);
+                            const int wm = k == 0 ? wm0 : wj[k - 1];
+                            if (actk && j >= 1 && (unsigned)(j - 1 - bp) <= pspan) {
+                                const int cnd = (wm >> 8) + s;
+                                if (cnd > m[k]) { m[k] = cnd; pmeta[k] = (pmeta[k] & ~255) | t; }
+                            }
+                            if (actk && (unsigned)(j - bp) <= pspan) {
+                                const int hj = wj[k] >> 8, g = wj[k] & 255;
+                                const int g1 = g & g1mask, g2 = g >> g1bits;
+                                const int c1 = hj - g1;
+                                if (c1 > ev1[k]) { ev1[k] = c1; pmeta[k] = (pmeta[k] & ~0xff00) | (t << 8); ofl[k] = (ofl[k] & 2) | (g1 == oe1 ? 1 : 0); }
+                                const int c2 = hj - g2;
+                                if (c2 > ev2[k]) { ev2[k] = c2; pmeta[k] = (pmeta[k] & ~0xff0000) | (t << 16); ofl[k] = (ofl[k] & 1) | (g2 == oe2 ? 2 : 0); }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) {
+                        int h = m[k];
+                        if (ev1[k] > h) { h = ev1[k]; hts[k] = 1; }
+                        if (ev2[k] > h) { h = ev2[k]; hts[k] = 2; }
+                        int u1 = h - ev1[k]; u1 = u1 < o1 ? u1 : o1;
+                        int u2 = h - ev2[k]; u2 = u2 < o2 ? u2 : o2;
+                        ht[k] = h;
+                        meta[k] = hts[k] | (ofl[k] << 2) | (u1 << 8) | (u2 << 16);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < CPT; k++) {
+                    const int j = j0 + k;
+                    const bool actk = (unsigned)(j - beg) <= span;
+                    const int a1 = actk ? ht[k] + e1 * j : POA_IDENT, a2 = actk ? ht[k] + e2 * j : POA_IDENT;
+                    agg1 = a1 > agg1 ? a1 : agg1;
+                    agg2 = a2 > agg2 ? a2 : agg2;
+                    if (k == CPT - 1) { alast1 = a1; alast2 = a2; }
+                }
+            }
+            stamp(1);
+            int i1 = POA_IDENT, i2 = POA_IDENT;
+            if (wave_act) {
+                i1 = poa_wave_scan_max(agg1);
+                i2 = poa_wave_scan_max(agg2);
+            }
+            if (lane == 63) {
+                sW1[buf * NW + wv] = i1; sW2[buf * NW + wv] = i2;
+                sL1[buf * NW + wv] = alast1; sL2[buf * NW + wv] = alast2;
+            }
+            stamp(2);
+            POA_LDS_BARRIER();
+            stamp(3);
+            int tw1[NW], tw2[NW];
+#pragma unroll
+            for (int q = 0; q < NW; q++) { tw1[q] = sW1[buf * NW + q]; tw2[q] = sW2[buf * NW + q]; }
+            int all1 = carry1, all2 = carry2;
+#pragma unroll
+            for (int q = 0; q < NW; q++) {
+                all1 = tw1[q] > all1 ? tw1[q] : all1;
+                all2 = tw2[q] > all2 ? tw2[q] : all2;
+            }
+            if (wave_act) {
+                int x1 = poa_wave_shr1(i1), x2 = poa_wave_shr1(i2);
+                int la1 = poa_wave_shr1(alast1), la2 = poa_wave_shr1(alast2);
+                if (lane == 0) {
+                    la1 = wv == 0 ? left1 : sL1[buf * NW + wv - 1];
+                    la2 = wv == 0 ? left2 : sL2[buf * NW + wv - 1];
+                }
+                int pre1 = carry1, pre2 = carry2;
+#pragma unroll
+                for (int q = 0; q < NW; q++) {
+                    if (q < wv) { pre1 = tw1[q] > pre1 ? tw1[q] : pre1; pre2 = tw2[q] > pre2 ? tw2[q] : pre2; }
+                }
+                int run1 = pre1 > x1 ? pre1 : x1;
+                int run2 = pre2 > x2 ? pre2 : x2;
+                if (lane_act) {
+                    int wv4[CPT], codev[CPT];
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) {
+                        const int j = j0 + k;
+                        const bool actk = (unsigned)(j - beg) <= span;
+                        const bool hasleft = j > beg;
+                        const int f1 = hasleft ? run1 - (o1 + e1 * j) : POA_NEG, f2 = hasleft ? run2 - (o2 + e2 * j) : POA_NEG;
+                        const int fo = hasleft ? ((run1 == la1 ? 16 : 0) | (run2 == la2 ? 32 : 0)) : 0;
+                        const int hf = ht[k] > f1 ? ht[k] : f1;
+                        const int h = hf > f2 ? hf : f2;
+                        const int hts = meta[k] & 3;
+                        const int lo4 = hts + (f2 > hf ? 6 : (f1 > ht[k] ? 3 : 0));
+                        codev[k] = lo4 | fo | (((meta[k] >> 2) & 3) << 6);
+                        const int dh = h - ht[k];
+                        int dd1 = ((meta[k] >> 8) & 255) + dh; dd1 = (dd1 < o1 ? dd1 : o1) + e1;
+                        int dd2 = ((meta[k] >> 16) & 255) + dh; dd2 = (dd2 < o2 ? dd2 : o2) + e2;
+                        wv4[k] = (int)(((uint32_t)h << 8) | (uint32_t)(dd1 | (dd2 << g1bits)));
+                        const int hb = actk ? h : INT32_MIN;
+                        if (hb > best) { best = hb; lpos = j; rpos = j; }
+                        else if (actk && hb == best) rpos = j;
+                        const int a1 = actk ? ht[k] + e1 * j : POA_IDENT, a2 = actk ? ht[k] + e2 * j : POA_IDENT;
+                        run1 = a1 > run1 ? a1 : run1;
+                        run2 = a2 > run2 ? a2 : run2;
+                        la1 = actk ? a1 : la1; la2 = actk ? a2 : la2;
+                    }
+                    const int4 wq = make_int4(wv4[0], wv4[1], wv4[2], wv4[3]);
+                    *(int4 *)(HG + j0) = wq;
+                    *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
+                    if (last) *(int4 *)(Vrow + c) = wq;
+                    if (np > 1) {
+                        *(uint32_t *)(drow + (uint64_t)W + c) = (uint32_t)(pmeta[0] & 255) | ((uint32_t)(pmeta[1] & 255) << 8) | ((uint32_t)(pmeta[2] & 255) << 16) | ((uint32_t)(pmeta[3] & 255) << 24);
+                        *(uint32_t *)(drow + 2ull * W + c) = (uint32_t)((pmeta[0] >> 8) & 255) | ((uint32_t)((pmeta[1] >> 8) & 255) << 8) | ((uint32_t)((pmeta[2] >> 8) & 255) << 16) | ((uint32_t)((pmeta[3] >> 8) & 255) << 24);
+                        *(uint32_t *)(drow + 3ull * W + c) = (uint32_t)((pmeta[0] >> 16) & 255) | ((uint32_t)((pmeta[1] >> 16) & 255) << 8) | ((uint32_t)((pmeta[2] >> 16) & 255) << 16) | ((uint32_t)((pmeta[3] >> 16) & 255) << 24);
+                    }
+                }
+            }
+            carry1 = all1; carry2 = all2;
+            left1 = sL1[buf * NW + nw_step - 1]; left2 = sL2[buf * NW + nw_step - 1];
+        }
+        stamp(4);
+        {
+            int wb = poa_wave_scan_max(best);
+            wb = __builtin_amdgcn_readlane(wb, 63);
+            int lm = best == wb ? -lpos : POA_IDENT;
+            int rm = best == wb ? rpos : POA_IDENT;
+            lm = poa_wave_scan_max(lm);
+            rm = poa_wave_scan_max(rm);
+            if (lane == 63) { sRed[wv * 3 + 0] = wb; sRed[wv * 3 + 1] = -lm; sRed[wv * 3 + 2] = rm; }
+        }
+        POA_LDS_BARRIER();
+        {
+            int rb[NW], rl[NW], rr[NW];
+#pragma unroll
+            for (int q = 0; q < NW; q++) { rb[q] = sRed[q * 3]; rl[q] = sRed[q * 3 + 1]; rr[q] = sRed[q * 3 + 2]; }
+            best = rb[0]; lpos = rl[0]; rpos = rr[0];
+#pragma unroll
+            for (int q = 1; q < NW; q++) {
+                if (rb[q] > best) { best = rb[q]; lpos = rl[q]; rpos = rr[q]; }
+                else if (rb[q] == best) { lpos = rl[q] < lpos ? rl[q] : lpos; rpos = rr[q] > rpos ? rr[q] : rpos; }
+            }
+        }
+        lpos = __builtin_amdgcn_readfirstlane(lpos);
+        rpos = __builtin_amdgcn_readfirstlane(rpos);
+        if (tid == 0) { vlmax[r] = lpos; vrmax[r] = rpos; }
+        prev_beg = beg; prev_end = end; prev_lmax = lpos; prev_rmax = rpos;
+        stamp(5);
+    }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        out_cells[blockIdx.x] = cells;
+        out_vcells[blockIdx.x] = vcells;
+        if constexpr (STAMP) {
+            if (stamps && blockIdx.x < 64)
+                for (int s = 0; s < 6; s++) stamps[blockIdx.x * 6 + s] = tacc[s];
+        }
+        if (failed) {
+            out_status[blockIdx.x] = POA_ST_POOL;
+            out_score[blockIdx.x] = POA_NEG;
+            out_row[blockIdx.x] = 0;
+        } else {
+            int bestv = INT32_MIN;
+            uint32_t brow = 0;
+            bool have = false;
+            for (uint32_t t = 0; t < pb.n_sink; t++) {
+                const uint32_t p = sink_preds[pb.sink0 + t];
+                const int bp = vbeg[p], ep = vend[p];
+                int val = POA_NEG;
+                if (qlen >= bp && qlen <= ep) val = ((const int32_t *)(pool + vvoff[p]))[qlen - (bp & ~3)] >> 8;
+                if (!have || val > bestv) { bestv = val; brow = p; have = true; }
+            }
+            out_score[blockIdx.x] = bestv;
+            out_row[blockIdx.x] = brow;
+            out_status[blockIdx.x] = (have && bestv > POA_NEG / 2) ? POA_ST_OK : POA_ST_NOALN;
+        }
+    }
+}
+
+static inline size_t poa_pk_lds_bytes(uint32_t lds_cols, int nt)
+{
+    const int nw = nt / 64;
+    return 4ull * lds_cols + lds_cols / 2 + (size_t)(8 * nw + 3 * nw + 2) * 4 + 16;
+}
+
 static inline uint32_t poa_lds_cols(uint32_t max_q) { return ((max_q + 1 + 15u) & ~15u) + 16u; }
 
 static inline size_t poa_lds_bytes(uint32_t lds_cols, int nt)
@@ -801,8 +1265,14 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     uint32_t max_q = 0;
     for (uint64_t p = 0; p < n; p++) max_q = std::max(max_q, G[p].qlen);
     const uint32_t lds_cols_all = poa_lds_cols(max_q);
-    if (poa_lds_bytes(lds_cols_all, 128) > 160 * 1024 - 256)
-        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query of %u bases: the LDS-resident POA kernel handles up to ~22 kbp", max_q);
+    {
+        int g1b = 0, g2b = 0;
+        while ((1 << g1b) <= params->gap_open1 + params->gap_ext1) g1b++;
+        while ((1 << g2b) <= params->gap_open2 + params->gap_ext2) g2b++;
+        const size_t need = g1b + g2b <= 8 ? poa_pk_lds_bytes(lds_cols_all, 128) : poa_lds_bytes(lds_cols_all, 128);
+        if (need > 160 * 1024 - 256)
+            return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query of %u bases does not fit the LDS-resident POA kernel (limit ~35 kbp, ~22 kbp with large gap penalties)", max_q);
+    }
     tr.mark("node tables (host threads)");
 
     // ---- flatten into pinned staging (offsets first, then a parallel fill)
@@ -938,40 +1408,56 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             uint32_t mq = 0;
             for (uint64_t i = i0; i < i1; i++) mq = std::max(mq, G[order[i]].qlen);
             const uint32_t lds_cols = poa_lds_cols(mq);
-            const char *force = getenv("VGA_POA_KERNEL");  // "lds128" | "lds256" | "lds512" (testing)
+            // VGA_POA_KERNEL (testing): "unpacked" selects k_poa_dp_lds, "128" / "256" / "512" pin the workgroup size
+            const char *force = getenv("VGA_POA_KERNEL");
+            int g1bits = 0, g2bits = 0;
+            while ((1 << g1bits) <= P.o1 + P.e1) g1bits++;
+            while ((1 << g2bits) <= P.o2 + P.e2) g2bits++;
+            const bool packed = g1bits + g2bits <= 8 && !(force && strstr(force, "unpacked"));
             int nt = mq >= 3072 ? 512 : (mq >= 768 ? 256 : 128);
             if (force) {
-                if (!strcmp(force, "lds128")) nt = 128;
-                else if (!strcmp(force, "lds256")) nt = 256;
-                else if (!strcmp(force, "lds512")) nt = 512;
+                if (strstr(force, "128")) nt = 128;
+                else if (strstr(force, "256")) nt = 256;
+                else if (strstr(force, "512")) nt = 512;
             }
-            while (nt > 128 && poa_lds_bytes(lds_cols, nt) > 160 * 1024 - 256) nt /= 2;
-            const size_t lds = poa_lds_bytes(lds_cols, nt);
+            auto lds_of = [&](int t) { return packed ? poa_pk_lds_bytes(lds_cols, t) : poa_lds_bytes(lds_cols, t); };
+            while (nt > 128 && lds_of(nt) > 160 * 1024 - 256) nt /= 2;
+            const size_t lds = lds_of(nt);
 #define POA_ARGS W.d_probs.p + i0, W.d_q.p, W.d_ntab.p, W.d_seq32.p, W.d_preds.p, W.d_sink.p, P, W.d_beg.p, W.d_end.p, W.d_doff.p,   \
                  W.d_voff.p, W.d_lmax.p, W.d_rmax.p, W.d_info.p, W.pool, W.d_next.p, W.pool_size, W.d_score.p + i0, W.d_row.p + i0, \
                  W.d_status.p + i0, W.d_cells.p + i0, W.d_vcells.p + i0, lds_cols
-            if (nt == 128) {
+            if (packed) {
+                if (getenv("VGA_POA_STAMPS") && nt == 512) {
+                    // diagnostic: per-segment cycle shares of the first 64 workgroups (tid 0's wave), printed to stderr
+                    static unsigned long long *d_st = nullptr;
+                    if (!d_st) chk(hipMalloc((void **)&d_st, 64 * 6 * 8));
+                    chk(hipMemsetAsync(d_st, 0, 64 * 6 * 8, st));
+                    chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((k_poa_dp_pk<512, true>), dim3(nb), dim3(512), lds, st, POA_ARGS, g1bits, d_st);
+                    unsigned long long h_st[64 * 6];
+                    chk(hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, st));
+                    chk(hipStreamSynchronize(st));
+                    unsigned long long sum[6] = {0, 0, 0, 0, 0, 0}, tot = 0;
+                    for (int b2 = 0; b2 < 64 && b2 < (int)nb; b2++)
+                        for (int s = 0; s < 6; s++) { sum[s] += h_st[b2 * 6 + s]; tot += h_st[b2 * 6 + s]; }
+                    fprintf(stderr, "[vga-stamps] cycles: prologue %llu phase1 %llu scans %llu step-barrier %llu phase2 %llu row-reduce+barrier %llu (total %llu)\n",
+                            sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], tot);
+                } else if (nt == 128) {
+                    chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((k_poa_dp_pk<128>), dim3(nb), dim3(128), lds, st, POA_ARGS, g1bits);
+                } else if (nt == 256) {
+                    chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((k_poa_dp_pk<256>), dim3(nb), dim3(256), lds, st, POA_ARGS, g1bits);
+                } else {
+                    chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((k_poa_dp_pk<512>), dim3(nb), dim3(512), lds, st, POA_ARGS, g1bits);
+                }
+            } else if (nt == 128) {
                 chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<128, 4>), dim3(nb), dim3(128), lds, st, POA_ARGS);
             } else if (nt == 256) {
                 chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<256, 4>), dim3(nb), dim3(256), lds, st, POA_ARGS);
-            } else if (getenv("VGA_POA_STAMPS")) {
-                // diagnostic: per-segment cycle shares of the first 64 workgroups (tid 0's wave), printed to stderr
-                static unsigned long long *d_st = nullptr;
-                if (!d_st) chk(hipMalloc((void **)&d_st, (64 * 6 + 4) * 8));
-                chk(hipMemsetAsync(d_st, 0, (64 * 6 + 4) * 8, st));
-                chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<512, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((k_poa_dp_lds<512, 4, true>), dim3(nb), dim3(512), lds, st, POA_ARGS, d_st);
-                unsigned long long h_st[64 * 6 + 4];
-                chk(hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, st));
-                chk(hipStreamSynchronize(st));
-                unsigned long long sum[6] = {0, 0, 0, 0, 0, 0}, tot = 0;
-                for (int b2 = 0; b2 < 64 && b2 < (int)nb; b2++)
-                    for (int s = 0; s < 6; s++) { sum[s] += h_st[b2 * 6 + s]; tot += h_st[b2 * 6 + s]; }
-                fprintf(stderr, "[vga-stamps] cycles: prologue %llu phase1 %llu scans %llu step-barrier %llu phase2 %llu row-reduce+barrier %llu (total %llu)\n",
-                        sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], tot);
-                fprintf(stderr, "[vga-stamps] workgroup 0: rows %llu, far rows %llu, multi-predecessor rows %llu, steps %llu\n", h_st[386], h_st[384], h_st[385], h_st[387]);
             } else {
                 chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<512, 4>), dim3(nb), dim3(512), lds, st, POA_ARGS);
