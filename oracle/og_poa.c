@@ -25,7 +25,7 @@
  *   - recurrences, with Ht = max(M, E1, E2) ("H before insertions"):
  *       M [r][j] = max_p H[p][j-1] + s(base_r, q_j)
  *       Ek[r][j] = max_p max(H[p][j] - (Ok+Ek), Ek[p][j] - Ek)          k = 1, 2
- *       Fk[r][j] = max_{beg <= j' < j} Ht[r][j'] - Ok - Ek*(j - j')      (OG_NEG at j = beg)
+ *       Fk[r][j] = max_{beg <= j' < j} Ht[r][j'] - Ok - Ek*(j - j')      (OG_IDENT - Ok - Ek*j at j = beg)
  *       H [r][j] = max(Ht, F1, F2)
  *     i.e. an insertion run opens from Ht only.  Opening it from a cell whose own value came from
  *     an insertion is dominated under a convex gap cost (O1,O2 >= 0, E2 <= E1), so H is unchanged,
@@ -35,6 +35,7 @@
  */
 #include "og_internal.h"
 
+#define OG_IDENT (INT32_MIN / 2)
 #define OG_NEG (-(1 << 21)) /* "minus infinity": far below any real score of a read up to ~100 kbp, small enough that the GPU kernel keeps H in 23 signed bits */
 
 void og_poa_default_params(og_poa_params *p)
@@ -243,10 +244,10 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
                 if (ve1 > vht) vht = ve1;
                 if (ve2 > vht) vht = ve2;
             }
-            if (have_run) {
-                vf1 = (int32_t)(run1 - P->gap_open1 - (int64_t)e1 * j);
-                vf2 = (int32_t)(run2 - P->gap_open2 - (int64_t)e2 * j);
-            }
+            /* the first column of a band has no left neighbour: its run is OG_IDENT ("minus infinity" of the scan),
+             * which keeps F far below any real or OG_NEG-derived value without a special case */
+            vf1 = (int32_t)((have_run ? run1 : (int64_t)OG_IDENT) - P->gap_open1 - (int64_t)e1 * j);
+            vf2 = (int32_t)((have_run ? run2 : (int64_t)OG_IDENT) - P->gap_open2 - (int64_t)e2 * j);
             vh = vht;
             if (vf1 > vh) vh = vf1;
             if (vf2 > vh) vh = vf2;

@@ -446,9 +446,8 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
                     for (int k = 0; k < CPT; k++) {
                         const int j = j0 + k;
                         const bool actk = (unsigned)(j - beg) <= span;
-                        const bool hasleft = j > beg;  // the first column of the band has no insertion predecessor
-                        const int f1 = hasleft ? run1 - (o1 + e1 * j) : POA_NEG, f2 = hasleft ? run2 - (o2 + e2 * j) : POA_NEG;
-                        const int fo = hasleft ? ((run1 == la1 ? 16 : 0) | (run2 == la2 ? 32 : 0)) : 0;
+                        const int f1 = run1 - (o1 + e1 * j), f2 = run2 - (o2 + e2 * j);  // run = POA_IDENT at the first column
+                        const int fo = (run1 == la1 ? 16 : 0) | (run2 == la2 ? 32 : 0);
                         const int hf = ht[k] > f1 ? ht[k] : f1;
                         const int h = hf > f2 ? hf : f2;
                         const int lo4 = hts[k] + (f2 > hf ? 6 : (f1 > ht[k] ? 3 : 0));
@@ -470,13 +469,8 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
                     for (int k = 0; k < CPT; k++) {
                         const int j = j0 + k;
                         const bool actk = j >= beg && j <= end;
-                        int f1 = POA_NEG, f2 = POA_NEG, fo1 = 0, fo2 = 0;
-                        if (j > beg) {
-                            f1 = run1 - o1 - e1 * j;
-                            f2 = run2 - o2 - e2 * j;
-                            fo1 = run1 == la1;
-                            fo2 = run2 == la2;
-                        }
+                        const int f1 = run1 - o1 - e1 * j, f2 = run2 - o2 - e2 * j;  // run = POA_IDENT at the first column
+                        const int fo1 = run1 == la1, fo2 = run2 == la2;
                         int h = ht[k], hs = hts[k];
                         if (f1 > h) { h = f1; hs = 3; }
                         if (f2 > h) { h = f2; hs = 4; }
@@ -1009,9 +1003,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                     for (int k = 0; k < CPT; k++) {
                         const int j = j0 + k;
                         const bool actk = (unsigned)(j - beg) <= span;
-                        const bool hasleft = j > beg;
-                        const int f1 = hasleft ? run1 - (o1 + e1 * j) : POA_NEG, f2 = hasleft ? run2 - (o2 + e2 * j) : POA_NEG;
-                        const int fo = hasleft ? ((run1 == la1 ? 16 : 0) | (run2 == la2 ? 32 : 0)) : 0;
+                        // at the first column run1/run2 are still POA_IDENT, which keeps F below everything (no special case)
+                        const int f1 = run1 - (o1 + e1 * j), f2 = run2 - (o2 + e2 * j);
+                        const int fo = (run1 == la1 ? 16 : 0) | (run2 == la2 ? 32 : 0);
                         const int hf = ht[k] > f1 ? ht[k] : f1;
                         const int h = hf > f2 ? hf : f2;
                         const int hts = meta[k] & 3;

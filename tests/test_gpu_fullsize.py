@@ -1,0 +1,170 @@
+"""Full-size runs (BASELINE.json config #2 / #3 shapes) checked through size-independent properties, without
+the oracle: every alignment must be internally consistent with the graph and the read it claims to explain."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import DATA, pkg
+
+pytestmark = pytest.mark.gpu
+DRB1 = os.path.join(DATA, "DRB1-3123.gfa")
+M, X, O1, E1, O2, E2 = 2, 4, 4, 2, 24, 1
+
+
+@pytest.fixture(scope="module")
+def env():
+    p = pkg()
+    hi = p.HostIndex.build_from_gfa(DRB1, 11)
+    ctx = p.Context(0)
+    hi.upload(ctx)
+    arr = hi.arrays()
+    yield p, hi, ctx, arr
+    ctx.close()
+
+
+def _gap(n):
+    return min(O1 + n * E1, O2 + n * E2)
+
+
+def _check_alignment(read, al, r, arr, edges_of):
+    """CIGAR/cs/path of read r: consumes the whole read, walks real edges, reproduces the read, and its score
+    recomputed from the operations equals best_score (the DP optimum cannot be beaten by its own traceback)."""
+    cig = [(int(n), op) for n, op in re.findall(r"(\d+)([MID])", al.cigar[r])]
+    nM = sum(n for n, op in cig if op == "M")
+    nI = sum(n for n, op in cig if op == "I")
+    nD = sum(n for n, op in cig if op == "D")
+    assert nM + nI == len(read), "CIGAR does not consume the read"
+    assert nM + nD == int(al.path_length[r]), "CIGAR does not span path_length graph bases"
+    assert nM == int(al.block_length[r])
+    hs = al.path_handles[int(al.path_off[r]):int(al.path_off[r + 1])].tolist()
+    assert all(h % 2 == 0 for h in hs)
+    ids = [h >> 1 for h in hs]
+    starts = arr["node_seq_idx"]
+    for a, b in zip(ids, ids[1:]):
+        assert b in edges_of(a), f"path uses a non-edge {a}->{b}"
+    # graph bases along the path
+    seq = arr["seq_fwd"]
+    pb = bytearray()
+    for t, nid in enumerate(ids):
+        s, e = int(starts[nid - 1]), int(starts[nid])
+        lo = int(al.path_start[r]) if t == 0 else 0
+        hi = int(al.path_end[r]) if t == len(ids) - 1 else e - s
+        pb += seq[s + lo:s + hi]
+    assert len(pb) == nM + nD, "node path and offsets do not add up to the aligned graph bases"
+    # replay cs against the path bases -> the read; recompute the score
+    cs = al.cs[r]
+    assert cs.startswith("cs:Z:")
+    gi, out, score = 0, bytearray(), 0
+    for m in re.finditer(r":(\d+)|\*([a-z])([a-z])|\+([a-z]+)|-([a-z]+)", cs[5:]):
+        if m.group(1):
+            n = int(m.group(1))
+            seg = pb[gi:gi + n]
+            out += seg
+            score += sum(M if chr(c) in "ACGT" else 0 for c in seg)
+            gi += n
+        elif m.group(2):
+            g, q = m.group(2).upper(), m.group(3).upper()
+            assert chr(pb[gi]) == g
+            out += q.encode()
+            score += -X if (g in "ACGT" and q in "ACGT") else 0
+            gi += 1
+        elif m.group(4):
+            out += m.group(4).upper().encode()
+            score -= _gap(len(m.group(4)))
+        else:
+            d = m.group(5).upper()
+            assert pb[gi:gi + len(d)] == d.encode()
+            gi += len(d)
+            score -= _gap(len(d))
+    assert gi == len(pb)
+    assert bytes(out).decode() == read, "cs + path do not reproduce the read"
+    # adjacent I and D runs may be scored by the DP as separate gaps only; the replay does the same
+    assert score == int(al.best_score[r]), f"score replay {score} != best_score {int(al.best_score[r])}"
+
+
+def _edges_of(arr):
+    ei, et, ed = arr["node_edge_idx"], arr["node_edges_to"], arr["edges"]
+
+    def f(nid):
+        s, e = int(ei[nid - 1]) + int(et[nid - 1]), int(ei[nid])
+        return {int(h) >> 1 for h in ed[s:e]}
+    return f
+
+
+def test_config2_full_map_only_properties(env):
+    """config #2: 1 000 x 150 bp reads, map-only"""
+    p, hi, ctx, arr = env
+    reads = p.readsim.config2_reads(DRB1, 1000)
+    seqs = [r.seq for r in reads]
+    mo = ctx.batch(seqs).map()
+    assert mo.n_reads == 1000
+    seq = arr["seq_fwd"]
+    k = 11
+    for r in range(0, 1000, 7):
+        a0, a1 = int(mo.anchor_off[r]), int(mo.anchor_off[r + 1])
+        te = mo.target_end[a0:a1]
+        assert np.all(np.diff(te.astype(np.int64)) >= 0), "anchors not sorted by target_end"
+        ids = mo.anchor_id[a0:a1]
+        assert sorted(ids.tolist()) == list(range(a1 - a0)), "anchor ids are not a permutation of 0..A-1"
+        # ties in target_end keep ascending ids (stable sort)
+        same = te[1:] == te[:-1]
+        assert np.all(ids[1:][same] > ids[:-1][same])
+        qb = mo.query_begin[a0:a1]
+        for i in range(a1 - a0):
+            tb_, te_ = int(mo.target_begin[a0 + i]), int(te[i])
+            if te_ - tb_ == k:  # single-node (or adjacent-node) anchor: the k-mer must be in the linearisation
+                assert seq[tb_:te_].decode() == seqs[r][int(qb[i]):int(qb[i]) + k]
+        f = mo.max_chain_score[a0:a1]
+        assert np.all(f >= k)
+        for ph, ch in mo.chains_of(r):
+            if ph:
+                continue
+            assert len(ch) >= 3 and ch == sorted(ch)
+            q = [int(qb[i]) for i in ch]
+            assert q == sorted(q) and len(set(q)) == len(q), "chain is not increasing in the query"
+            assert np.float64(f[ch[-1]]).tobytes() == np.float64(mo.curr_max[r]).tobytes()
+
+
+def test_config3_full_length_alignments_are_self_consistent(env):
+    """config #3 shape: 10 kbp ONT-profile reads, --also-align; 192 reads keep the host-side replay short"""
+    p, hi, ctx, arr = env
+    reads = p.readsim.config3_reads(DRB1, 192)
+    seqs = [r.seq for r in reads]
+    b = ctx.batch(seqs)
+    mo = b.map()
+    al = b.align(mo)
+    assert int(al.aligned.sum()) >= 190
+    edges_of = _edges_of(arr)
+    for r in range(len(seqs)):
+        if al.aligned[r]:
+            _check_alignment(seqs[r], al, r, arr, edges_of)
+    # idempotence: a second pass over the same batch gives identical records
+    al2 = b.align(b.map())
+    assert al2.cigar == al.cigar and al2.cs == al.cs and np.array_equal(al2.path_handles, al.path_handles)
+
+
+def test_host_map_reads_writes_reference_style_gaf(env, tmp_path):
+    """the C++ map_reads (src/map.rs:27-216): file naming and record shape, on a small real run"""
+    p, hi, ctx, arr = env
+    reads = p.readsim.simulate_reads(DRB1, 12, 800, 0.03, 0.03, 0.04, seed=21)
+    names, seqs = [r.name for r in reads], [r.seq for r in reads]
+    prefix = str(tmp_path / "out")
+    cg, ag, n_al = hi.map_reads(ctx, names, seqs, also_align=True, out_prefix=prefix)
+    assert open(prefix + "-chains.gaf").read() == cg and open(prefix + "-alignments.gaf").read() == ag
+    lines = ag.splitlines()
+    assert len(lines) == 12 and n_al == sum(1 for ln in lines if ln.split("\t")[5] != "*")
+    for ln, name, s in zip(lines, names, seqs):
+        f = ln.split("\t")
+        assert len(f) == 13 and f[0] == name and int(f[1]) == len(s)
+        if f[5] != "*":
+            assert (f[2], f[3], f[4], f[9], f[11]) == ("0", str(len(s)), "+", "0", "255")
+            assert f[12].startswith("as:i:-30 cs:Z:") and ",cg:Z:" in f[12]
+    for ln in cg.splitlines():
+        f = ln.split("\t")
+        assert len(f) == 13 and (f[5] == "*" or f[12].startswith("ta:Z:chain,n_anchors: "))
+    # a prefix ending in .gaf: the alignments overwrite the chains file (src/map.rs:135-139,174-178)
+    same = str(tmp_path / "both.gaf")
+    _, ag2, _ = hi.map_reads(ctx, names, seqs, also_align=True, out_prefix=same)
+    assert open(same).read() == ag2

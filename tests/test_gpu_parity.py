@@ -217,3 +217,29 @@ def test_align_config3_sample(oracle, ctx, drb1):
     upload_oracle_index(ctx, ix)
     _check_align(oracle, ctx, ix, pkg().readsim.simulate_reads(DRB1, 10, 2500, 0.03, 0.03, 0.04, seed=11))
     _check_align(oracle, ctx, ix, pkg().readsim.config3_reads(DRB1, 3))
+
+
+def test_poa_large_gap_penalties_use_the_unpacked_kernel(oracle, ctx):
+    """open+extend of the two gap pieces need more than 8 bits together -> k_poa_dp_lds (2-byte gap deltas)"""
+    rng = random.Random(7)
+    pp, op = pkg().default_poa_params(), oracle.default_poa_params()
+    for p_ in (pp, op):
+        p_.gap_open1, p_.gap_ext1, p_.gap_open2, p_.gap_ext2 = 6, 3, 200, 1
+    _check_poa(oracle, ctx, [_rand_problem(rng, 25, 10) for _ in range(25)] + [_rand_problem(rng, 60, 60) for _ in range(3)], pp, op)
+
+
+def test_unsupported_inputs_fail_loudly(oracle, ctx, drb1):
+    p = pkg()
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    mp = p.default_map_params()
+    mp.bandwidth = 100
+    with pytest.raises(p.VgaError) as e:
+        ctx.batch(["ACGT" * 10]).map(mp)
+    assert e.value.code == -4
+    mp = p.default_map_params()
+    mp.only_forward = 0
+    with pytest.raises(p.VgaError):
+        ctx.batch(["ACGT" * 10]).map(mp)
+    with pytest.raises(p.VgaError):  # edge with src >= dst
+        ctx.poa_batch([(["AC", "GT"], [(1, 0)], "ACGT")])
