@@ -117,7 +117,8 @@ def main():
         try:
             tj = json.load(open(tp))
             if tj.get("kernel") == dom and tj.get("reads") == args.reads and tj.get("read_len") == args.read_len:
-                traffic = tj.get("hbm_bytes_per_launch")
+                # measured with rocprofv3 PMC passes (profiles/traffic.json), per step; per launch = / launches per step
+                traffic = int(tj["hbm_bytes_per_step"] / max(d["launches"] / args.steps, 1))
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1379,6 +1379,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     P.match = params->match; P.mismatch = params->mismatch; P.o1 = params->gap_open1; P.e1 = params->gap_ext1;
     P.o2 = params->gap_open2; P.e2 = params->gap_ext2; P.banded = params->wb >= 0;
 
+    bool packed_all = true;  // value rows are 4 B per cell with the packed kernel, 6 B otherwise (byte model)
     int t_total = vga_timer_begin(ctx, "poa_total", 0);
     struct sub_t { uint64_t i0, i1; double raw_est; };
     hipError_t launch_err = hipSuccess;
@@ -1408,6 +1409,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             while ((1 << g1bits) <= P.o1 + P.e1) g1bits++;
             while ((1 << g2bits) <= P.o2 + P.e2) g2bits++;
             const bool packed = g1bits + g2bits <= 8 && !(force && strstr(force, "unpacked"));
+            packed_all = packed_all && packed;
             int nt = mq >= 3072 ? 512 : (mq >= 768 ? 256 : 128);
             if (force) {
                 if (strstr(force, "128")) nt = 128;
@@ -1584,14 +1586,14 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     POA_CHECK(hipStreamSynchronize(st));
     vga_timers_collect(ctx);
     // byte model of the DP kernel: graph bases + query + 1 direction byte per cell
-    // + the 6-byte value rows of node-end bases, written once and read back at least once
+    // + the value rows of node-end bases (4 B per cell packed, 6 B otherwise), written once and read back at least once
     uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
     for (uint64_t i = 0; i < n; i++) {
         all_cells += W.h_cells.p[i]; all_vcells += W.h_vcells.p[i]; all_ops += W.h_nops.p[i];
         all_rows += G[i].N; all_q += G[i].qlen;
     }
     for (auto &a : ctx->last_times) {
-        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + 12 * all_vcells;
+        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + (packed_all ? 8 : 12) * all_vcells;
         if (a.name == "poa_traceback") a.bytes = 6 * all_ops;
     }
     tm.ms_dp = vga_timer_sum(ctx, "poa_band_dp");
