@@ -83,16 +83,17 @@ __device__ __forceinline__ int poa_dpp(int old, int v)
 {
     return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
 }
-// wave64 inclusive max-scan (the sequence LLVM's atomic optimizer emits for gfx9)
+// wave64 inclusive max-scan (the sequence LLVM's atomic optimizer emits for gfx9).  `old` is the identity of signed
+// max so that the DPP combiner folds each stage into a single v_max_i32_dpp.
 __device__ __forceinline__ int poa_wave_scan_max(int v)
 {
     int t;
-    t = poa_dpp<0x111, 0xf>(POA_IDENT, v); v = t > v ? t : v;  // row_shr:1
-    t = poa_dpp<0x112, 0xf>(POA_IDENT, v); v = t > v ? t : v;  // row_shr:2
-    t = poa_dpp<0x114, 0xf>(POA_IDENT, v); v = t > v ? t : v;  // row_shr:4
-    t = poa_dpp<0x118, 0xf>(POA_IDENT, v); v = t > v ? t : v;  // row_shr:8
-    t = poa_dpp<0x142, 0xa>(POA_IDENT, v); v = t > v ? t : v;  // row_bcast:15 -> rows 1,3
-    t = poa_dpp<0x143, 0xc>(POA_IDENT, v); v = t > v ? t : v;  // row_bcast:31 -> rows 2,3
+    t = poa_dpp<0x111, 0xf>(INT32_MIN, v); v = t > v ? t : v;  // row_shr:1
+    t = poa_dpp<0x112, 0xf>(INT32_MIN, v); v = t > v ? t : v;  // row_shr:2
+    t = poa_dpp<0x114, 0xf>(INT32_MIN, v); v = t > v ? t : v;  // row_shr:4
+    t = poa_dpp<0x118, 0xf>(INT32_MIN, v); v = t > v ? t : v;  // row_shr:8
+    t = poa_dpp<0x142, 0xa>(INT32_MIN, v); v = t > v ? t : v;  // row_bcast:15 -> rows 1,3
+    t = poa_dpp<0x143, 0xc>(INT32_MIN, v); v = t > v ? t : v;  // row_bcast:31 -> rows 2,3
     return v;
 }
 __device__ __forceinline__ int poa_wave_shr1(int v) { return poa_dpp<0x138, 0xf>(POA_IDENT, v); }  // wave_shr:1
@@ -447,11 +448,11 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
                         const int j = j0 + k;
                         const bool actk = (unsigned)(j - beg) <= span;
                         const int f1 = run1 - (o1 + e1 * j), f2 = run2 - (o2 + e2 * j);  // run = POA_IDENT at the first column
-                        const int fo = (run1 == la1 ? 16 : 0) | (run2 == la2 ? 32 : 0);
+                        const int fo = (run1 == la1 ? 64 : 0) | (run2 == la2 ? 128 : 0);
                         const int hf = ht[k] > f1 ? ht[k] : f1;
                         const int h = hf > f2 ? hf : f2;
-                        const int lo4 = hts[k] + (f2 > hf ? 6 : (f1 > ht[k] ? 3 : 0));
-                        codev[k] = lo4 | fo | (ofl[k] << 6);
+                        const int fsel = f2 > hf ? 32 : (f1 > ht[k] ? 16 : 0);
+                        codev[k] = hts[k] | (ofl[k] << 2) | fsel | fo;
                         int dd1 = h - ev1[k]; dd1 = (dd1 < o1 ? dd1 : o1) + e1;
                         int dd2 = h - ev2[k]; dd2 = (dd2 < o2 ? dd2 : o2) + e2;
                         hv[k] = h;
@@ -474,8 +475,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
                         int h = ht[k], hs = hts[k];
                         if (f1 > h) { h = f1; hs = 3; }
                         if (f2 > h) { h = f2; hs = 4; }
-                        const int lo4 = hs < 3 ? hs : 3 + (hs - 3) * 3 + hts[k];
-                        codev[k] = lo4 | (fo1 << 4) | (fo2 << 5) | (ofl[k] << 6);
+                        codev[k] = hts[k] | (ofl[k] << 2) | (hs >= 3 ? (hs - 2) << 4 : 0) | (fo1 << 6) | (fo2 << 7);
                         int dd1 = h - ev1[k]; dd1 = (dd1 < o1 ? dd1 : o1) + e1;
                         int dd2 = h - ev2[k]; dd2 = (dd2 < o2 ? dd2 : o2) + e2;
                         hv[k] = h;
@@ -603,9 +603,11 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
         if (j < beg || j > end) { bad = true; break; }
         const uint64_t c = (uint64_t)(j - bal);
         const int code = pool[doff + c];
-        const int lo4 = code & 15;
-        const int hs = lo4 < 3 ? lo4 : 3 + (lo4 - 3) / 3;
-        const int hts = lo4 < 3 ? lo4 : (lo4 - 3) % 3;
+        // direction byte: [1:0] source of Ht (M, E1, E2), [3:2] E1/E2 opened here, [5:4] F chosen for H (0 none, 1 F1,
+        // 2 F2), [7:6] F1/F2 opened here
+        const int hts = code & 3;
+        const int fsel = (code >> 4) & 3;
+        const int hs = fsel ? 2 + fsel : hts;
         const int src = st == 0 ? hs : (st == 5 ? hts : st);
         if (nops + 1 >= cap) { bad = true; break; }
         if (src == 0) {
@@ -617,12 +619,12 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
         } else if (src == 1 || src == 2) {
             const int t = np > 1 ? pool[doff + (src == 1 ? 2 : 3) * W + c] : 0;
             const uint32_t p = first ? (np == 1 ? inf.x : preds[pb.pred0 + inf.x + t]) : i - 1;
-            const int open = (code >> (src == 1 ? 6 : 7)) & 1;
+            const int open = (code >> (src == 1 ? 2 : 3)) & 1;
             po[nops] = 2; pr[nops] = i; nops++;
             st = open ? 0 : src;
             i = p;
         } else {
-            const int open = (code >> (src == 3 ? 4 : 5)) & 1;
+            const int open = (code >> (src == 3 ? 6 : 7)) & 1;
             if (j - 1 < beg) { bad = true; break; }
             po[nops] = 1; pr[nops] = 0; nops++;
             st = open ? 5 : src;
@@ -666,17 +668,14 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int32_t *HG = (int32_t *)smem;                               // [lds_cols] (H << 8) | g
     uint16_t *Qn = (uint16_t *)(smem + 4ull * lds_cols);         // [lds_cols / 4] four column codes per halfword
-    int32_t *scr = (int32_t *)(smem + 4ull * lds_cols + lds_cols / 2);  // lds_cols is a multiple of 16
-    int32_t *sW1 = scr;               // [2][NW]
-    int32_t *sW2 = sW1 + 2 * NW;
-    int32_t *sL1 = sW2 + 2 * NW;
-    int32_t *sL2 = sL1 + 2 * NW;
-    int32_t *sRed = sL2 + 2 * NW;     // [NW][3]
-    int32_t *edgeW = sRed + 3 * NW;   // [2]
+    int4 *sX = (int4 *)(smem + 4ull * lds_cols + ((lds_cols / 2 + 15u) & ~15u));  // [2][NW] {scan1, scan2, last1, last2} per wave
+    int4 *sRed = sX + 2 * NW;         // [NW] {row max, -leftmost, rightmost, 0} per wave
+    int32_t *edgeW = (int32_t *)(sRed + NW);  // [2]
     unsigned long long *s_alloc = (unsigned long long *)(edgeW + 2);
+    const int edge_idx = (int)(edgeW - HG);  // edgeW addressed through HG, see phase 1
 
     const poa_prob pb = probs[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qlen = (int)pb.qlen;
     const char *query = queries + pb.q0;
     const uint4 *ntab = node_tab + pb.node0;
@@ -692,6 +691,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
     const int o1 = P.o1, e1 = P.e1, o2 = P.o2, e2 = P.e2;
     const int oe1 = o1 + e1, oe2 = o2 + e2;
     const int g1mask = (1 << g1bits) - 1;
+    const int g2w = 8 - g1bits;
     const int bw = (int)pb.w;
     unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int seg) {
@@ -709,7 +709,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
         __syncthreads();
         if (tid == 0) *s_alloc = atomicAdd(pool_next, (unsigned long long)POA_CHUNK);
         __syncthreads();
-        uint64_t b = *s_alloc;
+        const uint64_t bv = *s_alloc;  // uniform: keep the allocator state in scalar registers
+        const uint64_t b = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bv >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv);
         if (b + POA_CHUNK > pool_size) failed = true;
         cur = b;
         end = b + POA_CHUNK;
@@ -722,22 +724,25 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
         return r;
     };
 
-    // column codes: nibble j = code of query[j-1] (0..3 = ACGT, 4 = anything else incl. column 0)
+    // column codes, one-hot: nibble j = 1/2/4/8 for query[j-1] = A/C/G/T, 0 for anything else (and for column 0)
+    int non_acgt = 0;
     for (int t = tid; t < (int)(lds_cols / 4); t += NT) {
         uint32_t hw = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int j = 4 * t + k;
-            uint32_t code = 4;
+            uint32_t code = 0;
             if (j >= 1 && j <= qlen) {
                 const char ch = query[j - 1];
-                code = ch == 'A' ? 0u : (ch == 'C' ? 1u : (ch == 'G' ? 2u : (ch == 'T' ? 3u : 4u)));
+                code = ch == 'A' ? 1u : (ch == 'C' ? 2u : (ch == 'G' ? 4u : (ch == 'T' ? 8u : 0u)));
+                non_acgt |= code == 0;
             }
             hw |= code << (4 * k);
         }
         Qn[t] = (uint16_t)hw;
     }
-    __syncthreads();
+    // the branch-free interior path assumes every query base scores match or mismatch
+    const bool q_plain = __syncthreads_or(non_acgt) == 0;
 
     int prev_beg = 0, prev_end = -1, prev_lmax = 0, prev_rmax = 0;
     uint64_t cells = 0, vcells = 0;
@@ -809,6 +814,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
         uint8_t *drow = pool + doff;
         const int gcode = gb == 'A' ? 0 : (gb == 'C' ? 1 : (gb == 'G' ? 2 : (gb == 'T' ? 3 : 4)));
         const int sc_eq = gcode == 4 ? 0 : P.match, sc_ne = gcode == 4 ? 0 : -P.mismatch;
+        const int gsh = gcode & 3;            // bit of the one-hot column code that means "equal to this row's base"
+        const int sc_mm = sc_eq - sc_ne;
         // one predecessor (the row above in LDS, or a far row in HBM): the branch-free lean path applies
         const bool single = r > 0 && np == 1;
         const uint32_t sp = first ? ps : r - 1;  // that predecessor
@@ -839,8 +846,54 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
             int wold[CPT];  // this lane's LDS words (their low byte is rewritten together with H)
 #pragma unroll
             for (int k = 0; k < CPT; k++) { ht[k] = POA_NEG; meta[k] = (o1 << 8) | (o2 << 16); pmeta[k] = 0; wold[k] = 0; }
-            const uint32_t qn = wave_act ? (uint32_t)Qn[j0 >> 2] : 0x4444u;
-            if (wave_act && single) {
+            const uint32_t qn = wave_act ? (uint32_t)Qn[j0 >> 2] : 0u;
+            // Interior wave of a single-predecessor row: all of its 256 columns, and the column to their left, lie
+            // inside this row's band and the predecessor's, and every query base is A/C/G/T -> no per-cell masks.
+            const int jw0 = bal + c0 + 64 * CPT * wv;
+            const bool fastw = single && q_plain && jw0 > pbeg && jw0 >= beg && jw0 + 64 * CPT - 1 <= end && jw0 + 64 * CPT - 1 <= pend;
+            const int base1 = e1 * j0, base2 = e2 * j0;  // the max-plus scan runs on lane-relative values in the fast path
+            if (fastw) {
+                // ---------------- interior path, phase 1
+                int4 hv;
+                int hprev;
+                if (sp_near) {
+                    hv = *(const int4 *)(HG + j0);
+                    if (tid == NT - 1) edgeW[buf] = hv.w;
+                    // one LDS read through an index (a pointer select would turn into a flat load, which also waits
+                    // for the outstanding global stores)
+                    hprev = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : j0 - 1];
+                    asm volatile("" : "+v"(hprev));
+                    hprev >>= 8;
+                } else {
+                    hv = *(const int4 *)(Vp + (j0 - balp));
+                    hprev = Vp[j0 - balp - 1] >> 8;
+                }
+                const int wj[CPT] = {hv.x, hv.y, hv.z, hv.w};
+                const uint32_t eqb = qn >> gsh;
+                int ag1 = POA_IDENT, ag2 = POA_IDENT;
+#pragma unroll
+                for (int k = 0; k < CPT; k++) {
+                    const int hj = wj[k] >> 8;
+                    const int g1 = wj[k] & g1mask, g2 = (int)__builtin_amdgcn_ubfe((uint32_t)wj[k], (uint32_t)g1bits, (uint32_t)g2w);
+                    const int m = (hprev + sc_ne) + (int)((eqb >> (4 * k)) & 1u) * sc_mm;
+                    const int ev1 = hj - g1, ev2 = hj - g2;
+                    const int me = m > ev1 ? m : ev1;
+                    const int h = me > ev2 ? me : ev2;
+                    const int hts = ev2 > me ? 2 : (ev1 > m ? 1 : 0);
+                    const int ofl = (g1 == oe1 ? 4 : 0) | (g2 == oe2 ? 8 : 0);
+                    int u1 = h - ev1; u1 = u1 < o1 ? u1 : o1;
+                    int u2 = h - ev2; u2 = u2 < o2 ? u2 : o2;
+                    ht[k] = h;
+                    meta[k] = hts | ofl | (u1 << 8) | (u2 << 16);
+                    const int r1 = h + e1 * k, r2 = h + e2 * k;
+                    ag1 = r1 > ag1 ? r1 : ag1;
+                    ag2 = r2 > ag2 ? r2 : ag2;
+                    if (k == CPT - 1) { alast1 = r1 + base1; alast2 = r2 + base2; }
+                    hprev = hj;
+                }
+                agg1 = ag1 + base1;
+                agg2 = ag2 + base2;
+            } else if (wave_act && single) {
                 // ---------------- lean path, phase 1
                 int wj[CPT], wm0;
                 const unsigned pspan = (unsigned)(pend - pbeg);
@@ -849,7 +902,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                     wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
                     if (tid == NT - 1) edgeW[buf] = hv.w;
                     const int jm1 = j0 > 0 ? j0 - 1 : 0;
-                    wm0 = (tid == 0 && c0 > 0) ? edgeW[buf ^ 1] : HG[jm1];
+                    wm0 = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : jm1];
+                    asm volatile("" : "+v"(wm0));
                 } else {
                     const int idx = j0 - balp;
                     const int Wp = (pend - balp + 1 + 3) & ~3;
@@ -866,7 +920,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                     const bool inj = (unsigned)(j - pbeg) <= pspan;
                     const bool actk = (unsigned)(j - beg) <= span;
                     const int qc = (int)((qn >> (4 * k)) & 15u);
-                    const int s = qc == gcode ? sc_eq : (qc == 4 ? 0 : sc_ne);
+                    const int s = ((qc >> gsh) & 1) ? sc_eq : (qc == 0 ? 0 : sc_ne);
                     const int wm = k == 0 ? wm0 : wj[k - 1];
                     const int hj = wj[k] >> 8, g = wj[k] & 255;
                     const int g1 = g & g1mask, g2 = g >> g1bits;
@@ -906,7 +960,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                             wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
                             if (tid == NT - 1) edgeW[buf] = hv.w;
                             const int jm1 = j0 > 0 ? j0 - 1 : 0;
-                            wm0 = (tid == 0 && c0 > 0) ? edgeW[buf ^ 1] : HG[jm1];
+                            wm0 = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : jm1];
+                            asm volatile("" : "+v"(wm0));
                         } else {
                             bp = vbeg[p]; ep = vend[p];
                             const int32_t *Vq = (const int32_t *)(pool + vvoff[p]);
@@ -924,7 +979,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                             const int j = j0 + k;
                             const bool actk = (unsigned)(j - beg) <= span;
                             const int qc = (int)((qn >> (4 * k)) & 15u);
-                            const int s = qc == gcode ? sc_eq : (qc == 4 ? 0 : sc_ne);
+                            const int s = ((qc >> gsh) & 1) ? sc_eq : (qc == 0 ? 0 : sc_ne);
                             const int wm = k == 0 ? wm0 : wj[k - 1];
                             if (actk && j >= 1 && (unsigned)(j - 1 - bp) <= pspan) {
                                 const int cnd = (wm >> 8) + s;
@@ -967,37 +1022,69 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                 i1 = poa_wave_scan_max(agg1);
                 i2 = poa_wave_scan_max(agg2);
             }
-            if (lane == 63) {
-                sW1[buf * NW + wv] = i1; sW2[buf * NW + wv] = i2;
-                sL1[buf * NW + wv] = alast1; sL2[buf * NW + wv] = alast2;
-            }
+            if (lane == 63) sX[buf * NW + wv] = make_int4(i1, i2, alast1, alast2);
             stamp(2);
             POA_LDS_BARRIER();
             stamp(3);
-            int tw1[NW], tw2[NW];
-#pragma unroll
-            for (int q = 0; q < NW; q++) { tw1[q] = sW1[buf * NW + q]; tw2[q] = sW2[buf * NW + q]; }
-            int all1 = carry1, all2 = carry2;
-#pragma unroll
-            for (int q = 0; q < NW; q++) {
-                all1 = tw1[q] > all1 ? tw1[q] : all1;
-                all2 = tw2[q] > all2 ? tw2[q] : all2;
+            // lane q < NW picks up wave q's totals; an 8-lane DPP scan gives every wave its prefix and the step total
+            int4 xw = make_int4(INT32_MIN, INT32_MIN, POA_IDENT, POA_IDENT);
+            if (lane < NW) xw = sX[buf * NW + lane];
+            int t1 = xw.x, t2 = xw.y, t;
+            t = poa_dpp<0x111, 0xf>(INT32_MIN, t1); t1 = t > t1 ? t : t1;
+            t = poa_dpp<0x111, 0xf>(INT32_MIN, t2); t2 = t > t2 ? t : t2;
+            if (NW > 2) {
+                t = poa_dpp<0x112, 0xf>(INT32_MIN, t1); t1 = t > t1 ? t : t1;
+                t = poa_dpp<0x112, 0xf>(INT32_MIN, t2); t2 = t > t2 ? t : t2;
             }
+            if (NW > 4) {
+                t = poa_dpp<0x114, 0xf>(INT32_MIN, t1); t1 = t > t1 ? t : t1;
+                t = poa_dpp<0x114, 0xf>(INT32_MIN, t2); t2 = t > t2 ? t : t2;
+            }
+            const int tot1 = __builtin_amdgcn_readlane(t1, NW - 1), tot2 = __builtin_amdgcn_readlane(t2, NW - 1);
+            const int all1 = tot1 > carry1 ? tot1 : carry1, all2 = tot2 > carry2 ? tot2 : carry2;
+            const int nleft1 = __builtin_amdgcn_readlane(xw.z, nw_step - 1), nleft2 = __builtin_amdgcn_readlane(xw.w, nw_step - 1);
             if (wave_act) {
                 int x1 = poa_wave_shr1(i1), x2 = poa_wave_shr1(i2);
                 int la1 = poa_wave_shr1(alast1), la2 = poa_wave_shr1(alast2);
-                if (lane == 0) {
-                    la1 = wv == 0 ? left1 : sL1[buf * NW + wv - 1];
-                    la2 = wv == 0 ? left2 : sL2[buf * NW + wv - 1];
+                int pre1 = carry1, pre2 = carry2, pl1 = left1, pl2 = left2;
+                if (wv > 0) {
+                    const int p1 = __builtin_amdgcn_readlane(t1, wv - 1), p2 = __builtin_amdgcn_readlane(t2, wv - 1);
+                    pre1 = p1 > pre1 ? p1 : pre1;
+                    pre2 = p2 > pre2 ? p2 : pre2;
+                    pl1 = __builtin_amdgcn_readlane(xw.z, wv - 1);
+                    pl2 = __builtin_amdgcn_readlane(xw.w, wv - 1);
                 }
-                int pre1 = carry1, pre2 = carry2;
-#pragma unroll
-                for (int q = 0; q < NW; q++) {
-                    if (q < wv) { pre1 = tw1[q] > pre1 ? tw1[q] : pre1; pre2 = tw2[q] > pre2 ? tw2[q] : pre2; }
-                }
+                if (lane == 0) { la1 = pl1; la2 = pl2; }
                 int run1 = pre1 > x1 ? pre1 : x1;
                 int run2 = pre2 > x2 ? pre2 : x2;
-                if (lane_act) {
+                if (fastw) {
+                    // ---------------- interior path, phase 2
+                    int wv4[CPT], codev[CPT];
+                    int R1 = run1 - base1, R2 = run2 - base2, L1 = la1 - base1, L2 = la2 - base2;
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) {
+                        const int j = j0 + k;
+                        const int f1 = R1 - (o1 + e1 * k), f2 = R2 - (o2 + e2 * k);
+                        const int fo = (R1 == L1 ? 64 : 0) | (R2 == L2 ? 128 : 0);
+                        const int hf = ht[k] > f1 ? ht[k] : f1;
+                        const int h = hf > f2 ? hf : f2;
+                        const int fsel = f2 > hf ? 32 : (f1 > ht[k] ? 16 : 0);
+                        codev[k] = (meta[k] & 15) | fsel | fo;
+                        const int dh = h - ht[k];
+                        int dd1 = ((meta[k] >> 8) & 255) + dh; dd1 = (dd1 < o1 ? dd1 : o1) + e1;
+                        int dd2 = ((meta[k] >> 16) & 255) + dh; dd2 = (dd2 < o2 ? dd2 : o2) + e2;
+                        wv4[k] = (int)(((uint32_t)h << 8) | (uint32_t)(dd1 | (dd2 << g1bits)));
+                        if (h > best) { best = h; lpos = j; rpos = j; }
+                        else if (h == best) rpos = j;
+                        L1 = ht[k] + e1 * k; L2 = ht[k] + e2 * k;
+                        R1 = L1 > R1 ? L1 : R1;
+                        R2 = L2 > R2 ? L2 : R2;
+                    }
+                    const int4 wq = make_int4(wv4[0], wv4[1], wv4[2], wv4[3]);
+                    *(int4 *)(HG + j0) = wq;
+                    *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
+                    if (last) *(int4 *)(Vrow + c) = wq;
+                } else if (lane_act) {
                     int wv4[CPT], codev[CPT];
 #pragma unroll
                     for (int k = 0; k < CPT; k++) {
@@ -1005,12 +1092,11 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                         const bool actk = (unsigned)(j - beg) <= span;
                         // at the first column run1/run2 are still POA_IDENT, which keeps F below everything (no special case)
                         const int f1 = run1 - (o1 + e1 * j), f2 = run2 - (o2 + e2 * j);
-                        const int fo = (run1 == la1 ? 16 : 0) | (run2 == la2 ? 32 : 0);
+                        const int fo = (run1 == la1 ? 64 : 0) | (run2 == la2 ? 128 : 0);
                         const int hf = ht[k] > f1 ? ht[k] : f1;
                         const int h = hf > f2 ? hf : f2;
-                        const int hts = meta[k] & 3;
-                        const int lo4 = hts + (f2 > hf ? 6 : (f1 > ht[k] ? 3 : 0));
-                        codev[k] = lo4 | fo | (((meta[k] >> 2) & 3) << 6);
+                        const int fsel = f2 > hf ? 32 : (f1 > ht[k] ? 16 : 0);
+                        codev[k] = (meta[k] & 15) | fsel | fo;
                         const int dh = h - ht[k];
                         int dd1 = ((meta[k] >> 8) & 255) + dh; dd1 = (dd1 < o1 ? dd1 : o1) + e1;
                         int dd2 = ((meta[k] >> 16) & 255) + dh; dd2 = (dd2 < o2 ? dd2 : o2) + e2;
@@ -1035,32 +1121,41 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                 }
             }
             carry1 = all1; carry2 = all2;
-            left1 = sL1[buf * NW + nw_step - 1]; left2 = sL2[buf * NW + nw_step - 1];
+            left1 = nleft1; left2 = nleft2;
         }
         stamp(4);
         {
             int wb = poa_wave_scan_max(best);
             wb = __builtin_amdgcn_readlane(wb, 63);
-            int lm = best == wb ? -lpos : POA_IDENT;
-            int rm = best == wb ? rpos : POA_IDENT;
+            int lm = best == wb ? -lpos : INT32_MIN;
+            int rm = best == wb ? rpos : INT32_MIN;
             lm = poa_wave_scan_max(lm);
             rm = poa_wave_scan_max(rm);
-            if (lane == 63) { sRed[wv * 3 + 0] = wb; sRed[wv * 3 + 1] = -lm; sRed[wv * 3 + 2] = rm; }
+            if (lane == 63) sRed[wv] = make_int4(wb, lm, rm, 0);
         }
         POA_LDS_BARRIER();
         {
-            int rb[NW], rl[NW], rr[NW];
-#pragma unroll
-            for (int q = 0; q < NW; q++) { rb[q] = sRed[q * 3]; rl[q] = sRed[q * 3 + 1]; rr[q] = sRed[q * 3 + 2]; }
-            best = rb[0]; lpos = rl[0]; rpos = rr[0];
-#pragma unroll
-            for (int q = 1; q < NW; q++) {
-                if (rb[q] > best) { best = rb[q]; lpos = rl[q]; rpos = rr[q]; }
-                else if (rb[q] == best) { lpos = rl[q] < lpos ? rl[q] : lpos; rpos = rr[q] > rpos ? rr[q] : rpos; }
+            int4 rw = make_int4(INT32_MIN, INT32_MIN, INT32_MIN, 0);
+            if (lane < NW) rw = sRed[lane];
+            int b = rw.x, t;
+            t = poa_dpp<0x111, 0xf>(INT32_MIN, b); b = t > b ? t : b;
+            if (NW > 2) { t = poa_dpp<0x112, 0xf>(INT32_MIN, b); b = t > b ? t : b; }
+            if (NW > 4) { t = poa_dpp<0x114, 0xf>(INT32_MIN, b); b = t > b ? t : b; }
+            const int rbest = __builtin_amdgcn_readlane(b, NW - 1);
+            int lm = rw.x == rbest ? rw.y : INT32_MIN, rm = rw.x == rbest ? rw.z : INT32_MIN;
+            t = poa_dpp<0x111, 0xf>(INT32_MIN, lm); lm = t > lm ? t : lm;
+            t = poa_dpp<0x111, 0xf>(INT32_MIN, rm); rm = t > rm ? t : rm;
+            if (NW > 2) {
+                t = poa_dpp<0x112, 0xf>(INT32_MIN, lm); lm = t > lm ? t : lm;
+                t = poa_dpp<0x112, 0xf>(INT32_MIN, rm); rm = t > rm ? t : rm;
             }
+            if (NW > 4) {
+                t = poa_dpp<0x114, 0xf>(INT32_MIN, lm); lm = t > lm ? t : lm;
+                t = poa_dpp<0x114, 0xf>(INT32_MIN, rm); rm = t > rm ? t : rm;
+            }
+            lpos = -__builtin_amdgcn_readlane(lm, NW - 1);
+            rpos = __builtin_amdgcn_readlane(rm, NW - 1);
         }
-        lpos = __builtin_amdgcn_readfirstlane(lpos);
-        rpos = __builtin_amdgcn_readfirstlane(rpos);
         if (tid == 0) { vlmax[r] = lpos; vrmax[r] = rpos; }
         prev_beg = beg; prev_end = end; prev_lmax = lpos; prev_rmax = rpos;
         stamp(5);
@@ -1099,7 +1194,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
 static inline size_t poa_pk_lds_bytes(uint32_t lds_cols, int nt)
 {
     const int nw = nt / 64;
-    return 4ull * lds_cols + lds_cols / 2 + (size_t)(8 * nw + 3 * nw + 2) * 4 + 16;
+    return 4ull * lds_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw) * 16 + 2 * 4 + 8 + 16;
 }
 
 static inline uint32_t poa_lds_cols(uint32_t max_q) { return ((max_q + 1 + 15u) & ~15u) + 16u; }
@@ -1595,6 +1690,17 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     for (auto &a : ctx->last_times) {
         if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + (packed_all ? 8 : 12) * all_vcells;
         if (a.name == "poa_traceback") a.bytes = 6 * all_ops;
+    }
+    if (tr.on) {
+        // mean band width per problem (cells / rows), 256-column buckets
+        uint32_t hist[17] = {0};
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t wmean = W.h_cells.p[i] / (G[order[i]].N ? G[order[i]].N : 1);
+            hist[std::min<uint64_t>(wmean / 256, 16)]++;
+        }
+        fprintf(stderr, "[vga-trace] poa: mean band width histogram (256-column buckets):");
+        for (int b = 0; b < 17; b++) fprintf(stderr, " %u", hist[b]);
+        fprintf(stderr, "\n");
     }
     tm.ms_dp = vga_timer_sum(ctx, "poa_band_dp");
     tm.ms_tb = vga_timer_sum(ctx, "poa_traceback");
