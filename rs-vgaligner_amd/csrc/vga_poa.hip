@@ -653,22 +653,25 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
 //   * single-predecessor rows whose predecessor is not the row above ("far") use the lean path as well, with
 //     their five words coming from HBM instead of LDS.
 template <int NT, bool STAMP = false>
-__global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
+__global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
     const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
     poa_dev_params P, int32_t *row_beg, int32_t *row_end, uint64_t *row_doff, uint64_t *row_voff, int32_t *row_lmax,
     int32_t *row_rmax, uint2 *row_info, uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size,
     int32_t *__restrict__ out_score, uint32_t *__restrict__ out_row, int32_t *__restrict__ out_status,
-    uint64_t *__restrict__ out_cells, uint64_t *__restrict__ out_vcells, uint32_t lds_cols, int g1bits,
+    uint64_t *__restrict__ out_cells, uint64_t *__restrict__ out_vcells, uint32_t lds_cols, uint32_t hg_cols, uint32_t win_mask,
+    uint32_t *__restrict__ out_maxw, int g1bits,
     unsigned long long *stamps = nullptr)
 {
     constexpr int CPT = 4;
     constexpr int NW = NT / 64;
     constexpr int STEP = NT * CPT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    int32_t *HG = (int32_t *)smem;                               // [lds_cols] (H << 8) | g
-    uint16_t *Qn = (uint16_t *)(smem + 4ull * lds_cols);         // [lds_cols / 4] four column codes per halfword
-    int4 *sX = (int4 *)(smem + 4ull * lds_cols + ((lds_cols / 2 + 15u) & ~15u));  // [2][NW] {scan1, scan2, last1, last2} per wave
+    // HG is a window of hg_cols columns addressed by (column & win_mask): a power of two smaller than the query when
+    // the launch was sized for narrow bands (more workgroups per CU), or every column (win_mask = ~0).
+    int32_t *HG = (int32_t *)smem;                               // [hg_cols] (H << 8) | g
+    uint16_t *Qn = (uint16_t *)(smem + 4ull * hg_cols);          // [lds_cols / 4] four column codes per halfword
+    int4 *sX = (int4 *)(smem + 4ull * hg_cols + ((lds_cols / 2 + 15u) & ~15u));  // [2][NW] {scan1, scan2, last1, last2} per wave
     int4 *sRed = sX + 2 * NW;         // [NW] {row max, -leftmost, rightmost, 0} per wave
     int32_t *edgeW = (int32_t *)(sRed + NW);  // [2]
     unsigned long long *s_alloc = (unsigned long long *)(edgeW + 2);
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
     const int g1mask = (1 << g1bits) - 1;
     const int g2w = 8 - g1bits;
     const int bw = (int)pb.w;
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
     auto stamp = [&](int seg) {
         if constexpr (STAMP) {
             unsigned long long t;
@@ -705,6 +708,8 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
 
     uint64_t dcur = 0, dend = 0, vcur = 0, vendp = 0;
     bool failed = false;
+    bool prev_lds = true;  // the row just computed is resident in the LDS window (false after a row wider than the window)
+    int maxw = 0;
     auto take_chunk = [&](uint64_t &cur, uint64_t &end) {
         __syncthreads();
         if (tid == 0) *s_alloc = atomicAdd(pool_next, (unsigned long long)POA_CHUNK);
@@ -765,9 +770,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
             gb = (uint8_t)(seq_word >> (8u * (bi & 3u)));
         }
         stamp(-1);
-        bool far = false;
+        // a predecessor is "near" when it is the row directly above AND that row is still in the LDS window
+        bool far = r > 0 && !prev_lds;
         if (first) {
-            if (np == 1) far = ps != r - 1;
+            if (np == 1) far |= ps != r - 1;
             else
                 for (int t = 0; t < np; t++) far |= plist[ps + t] != r - 1;
         }
@@ -797,12 +803,17 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
         }
         const int bal = beg & ~3;
         const int W = (end - bal + 1 + 3) & ~3;  // storage width / plane stride
+        maxw = W > maxw ? W : maxw;
+        // A row wider than the LDS window (columns would alias) is not written to LDS: it keeps a value row in HBM like
+        // a node-end row does, and the row below reads it from there.
+        const bool wide = (uint32_t)W + 8u > hg_cols;
+        const bool keep = last || wide;
         if (r > 0) cells += (uint64_t)(end - beg + 1);
-        if (last) vcells += (uint64_t)(end - beg + 1);
+        if (keep) vcells += (uint64_t)(end - beg + 1);
         const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u));
         if (failed) break;
         uint64_t voff = 0;
-        if (last) { voff = alloc(vcur, vendp, 4ull * (uint64_t)W); if (failed) break; }
+        if (keep) { voff = alloc(vcur, vendp, 4ull * (uint64_t)W); if (failed) break; }
         if (tid == 0) {
             vbeg[r] = beg;
             vend[r] = end;
@@ -819,13 +830,19 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
         // one predecessor (the row above in LDS, or a far row in HBM): the branch-free lean path applies
         const bool single = r > 0 && np == 1;
         const uint32_t sp = first ? ps : r - 1;  // that predecessor
-        const bool sp_near = sp == r - 1;
+        const bool sp_near = sp == r - 1 && prev_lds;
         int pbeg = prev_beg, pend = prev_end;
         const int32_t *Vp = nullptr;
         int balp = 0;
         if (single && !sp_near) {
-            pbeg = vbeg[sp]; pend = vend[sp];
-            Vp = (const int32_t *)(pool + vvoff[sp]);
+            // uniform values of a far row: read them into scalar registers right here, so that their s_waitcnt vmcnt
+            // stays inside this branch (in shared code it would make every row wait for its predecessors' stores)
+            pbeg = __builtin_amdgcn_readfirstlane(vbeg[sp]);
+            pend = __builtin_amdgcn_readfirstlane(vend[sp]);
+            const uint64_t vo = vvoff[sp];
+            const uint64_t vos = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(vo >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vo);
+            Vp = (const int32_t *)(pool + vos);
             balp = pbeg & ~3;
         }
         stamp(0);
@@ -857,17 +874,22 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                 int4 hv;
                 int hprev;
                 if (sp_near) {
-                    hv = *(const int4 *)(HG + j0);
+                    hv = *(const int4 *)(HG + (j0 & win_mask));
                     if (tid == NT - 1) edgeW[buf] = hv.w;
                     // one LDS read through an index (a pointer select would turn into a flat load, which also waits
                     // for the outstanding global stores)
-                    hprev = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : j0 - 1];
+                    hprev = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : ((j0 - 1) & win_mask)];
                     asm volatile("" : "+v"(hprev));
                     hprev >>= 8;
                 } else {
                     hv = *(const int4 *)(Vp + (j0 - balp));
-                    hprev = Vp[j0 - balp - 1] >> 8;
+                    hprev = Vp[j0 - balp - 1];
+                    // consume the loads inside this branch: otherwise their s_waitcnt vmcnt lands in the code shared
+                    // with near rows, where it would also wait for every outstanding direction / value store
+                    asm volatile("" : "+v"(hv.x), "+v"(hv.y), "+v"(hv.z), "+v"(hv.w), "+v"(hprev));
+                    hprev >>= 8;
                 }
+                stamp(6);
                 const int wj[CPT] = {hv.x, hv.y, hv.z, hv.w};
                 const uint32_t eqb = qn >> gsh;
                 int ag1 = POA_IDENT, ag2 = POA_IDENT;
@@ -898,11 +920,11 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                 int wj[CPT], wm0;
                 const unsigned pspan = (unsigned)(pend - pbeg);
                 if (sp_near) {
-                    const int4 hv = *(const int4 *)(HG + j0);
+                    const int4 hv = *(const int4 *)(HG + (j0 & win_mask));
                     wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
                     if (tid == NT - 1) edgeW[buf] = hv.w;
                     const int jm1 = j0 > 0 ? j0 - 1 : 0;
-                    wm0 = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : jm1];
+                    wm0 = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : (jm1 & win_mask)];
                     asm volatile("" : "+v"(wm0));
                 } else {
                     const int idx = j0 - balp;
@@ -911,7 +933,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                     if (idx >= 0 && idx < Wp) hv = *(const int4 *)(Vp + idx);
                     wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
                     wm0 = (idx >= 1 && idx - 1 < Wp) ? Vp[idx - 1] : 0;
-                    // keep the in-place protocol of the LDS row intact for the next (near) row
+                    asm volatile("" : "+v"(wj[0]), "+v"(wj[1]), "+v"(wj[2]), "+v"(wj[3]), "+v"(wm0));  // wait here, not in shared code
                 }
                 bool inprev = j0 >= 1 && (unsigned)(j0 - 1 - pbeg) <= pspan;
 #pragma unroll
@@ -954,17 +976,21 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                         const uint32_t p = plist[ps + t];
                         int wj[CPT], wm0 = 0;
                         int bp, ep;
-                        if (p == r - 1) {
+                        if (p == r - 1 && prev_lds) {
                             bp = prev_beg; ep = prev_end;
-                            const int4 hv = *(const int4 *)(HG + j0);
+                            const int4 hv = *(const int4 *)(HG + (j0 & win_mask));
                             wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
                             if (tid == NT - 1) edgeW[buf] = hv.w;
                             const int jm1 = j0 > 0 ? j0 - 1 : 0;
-                            wm0 = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : jm1];
+                            wm0 = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : (jm1 & win_mask)];
                             asm volatile("" : "+v"(wm0));
                         } else {
-                            bp = vbeg[p]; ep = vend[p];
-                            const int32_t *Vq = (const int32_t *)(pool + vvoff[p]);
+                            bp = __builtin_amdgcn_readfirstlane(vbeg[p]);
+                            ep = __builtin_amdgcn_readfirstlane(vend[p]);
+                            const uint64_t vo = vvoff[p];
+                            const uint64_t vos = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(vo >> 32)) << 32) |
+                                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vo);
+                            const int32_t *Vq = (const int32_t *)(pool + vos);
                             const int balq = bp & ~3;
                             const int Wq = (ep - balq + 1 + 3) & ~3;
                             const int idx = j0 - balq;
@@ -972,6 +998,7 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                             if (idx >= 0 && idx < Wq) hv = *(const int4 *)(Vq + idx);
                             wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
                             wm0 = (idx >= 1 && idx - 1 < Wq) ? Vq[idx - 1] : 0;
+                            asm volatile("" : "+v"(wj[0]), "+v"(wj[1]), "+v"(wj[2]), "+v"(wj[3]), "+v"(wm0));  // wait here, not in shared code
                         }
                         const unsigned pspan = (unsigned)(ep - bp);
 #pragma unroll
@@ -1081,9 +1108,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                         R2 = L2 > R2 ? L2 : R2;
                     }
                     const int4 wq = make_int4(wv4[0], wv4[1], wv4[2], wv4[3]);
-                    *(int4 *)(HG + j0) = wq;
+                    if (!wide) *(int4 *)(HG + (j0 & win_mask)) = wq;
                     *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
-                    if (last) *(int4 *)(Vrow + c) = wq;
+                    if (keep) *(int4 *)(Vrow + c) = wq;
                 } else if (lane_act) {
                     int wv4[CPT], codev[CPT];
 #pragma unroll
@@ -1110,9 +1137,9 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
                         la1 = actk ? a1 : la1; la2 = actk ? a2 : la2;
                     }
                     const int4 wq = make_int4(wv4[0], wv4[1], wv4[2], wv4[3]);
-                    *(int4 *)(HG + j0) = wq;
+                    if (!wide) *(int4 *)(HG + (j0 & win_mask)) = wq;
                     *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
-                    if (last) *(int4 *)(Vrow + c) = wq;
+                    if (keep) *(int4 *)(Vrow + c) = wq;
                     if (np > 1) {
                         *(uint32_t *)(drow + (uint64_t)W + c) = (uint32_t)(pmeta[0] & 255) | ((uint32_t)(pmeta[1] & 255) << 8) | ((uint32_t)(pmeta[2] & 255) << 16) | ((uint32_t)(pmeta[3] & 255) << 24);
                         *(uint32_t *)(drow + 2ull * W + c) = (uint32_t)((pmeta[0] >> 8) & 255) | ((uint32_t)((pmeta[1] >> 8) & 255) << 8) | ((uint32_t)((pmeta[2] >> 8) & 255) << 16) | ((uint32_t)((pmeta[3] >> 8) & 255) << 24);
@@ -1158,17 +1185,20 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
         }
         if (tid == 0) { vlmax[r] = lpos; vrmax[r] = rpos; }
         prev_beg = beg; prev_end = end; prev_lmax = lpos; prev_rmax = rpos;
+        prev_lds = !wide;
         stamp(5);
     }
     }
     __syncthreads();
+    if constexpr (STAMP) {
+        // wave 0 holds the band's left edge; wave 2 is an interior wave on 10 kbp reads
+        if (stamps && blockIdx.x < 64 && (tid == 0 || tid == 128))
+            for (int s = 0; s < 8; s++) stamps[(tid ? 64 * 8 : 0) + blockIdx.x * 8 + s] = tacc[s];
+    }
     if (tid == 0) {
         out_cells[blockIdx.x] = cells;
         out_vcells[blockIdx.x] = vcells;
-        if constexpr (STAMP) {
-            if (stamps && blockIdx.x < 64)
-                for (int s = 0; s < 6; s++) stamps[blockIdx.x * 6 + s] = tacc[s];
-        }
+        out_maxw[blockIdx.x] = (uint32_t)maxw;
         if (failed) {
             out_status[blockIdx.x] = POA_ST_POOL;
             out_score[blockIdx.x] = POA_NEG;
@@ -1191,10 +1221,10 @@ __global__ __launch_bounds__(NT, (NT >= 512 ? 6 : 4)) void k_poa_dp_pk(
     }
 }
 
-static inline size_t poa_pk_lds_bytes(uint32_t lds_cols, int nt)
+static inline size_t poa_pk_lds_bytes(uint32_t hg_cols, uint32_t lds_cols, int nt)
 {
     const int nw = nt / 64;
-    return 4ull * lds_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw) * 16 + 2 * 4 + 8 + 16;
+    return 4ull * hg_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw) * 16 + 2 * 4 + 8 + 16;
 }
 
 static inline uint32_t poa_lds_cols(uint32_t max_q) { return ((max_q + 1 + 15u) & ~15u) + 16u; }
@@ -1285,7 +1315,7 @@ void poa_prepare(const poa_view &v, poa_prep &g)
 struct poa_ws {
     vga_dbuf<poa_prob> d_probs;
     vga_dbuf<uint4> d_ntab;
-    vga_dbuf<uint32_t> d_seq32, d_preds, d_sink, d_row, d_orow, d_nops;
+    vga_dbuf<uint32_t> d_seq32, d_preds, d_sink, d_row, d_orow, d_nops, d_maxw;
     vga_dbuf<uint8_t> d_ops;
     vga_dbuf<int32_t> d_beg, d_end, d_lmax, d_rmax, d_score, d_status;
     vga_dbuf<uint64_t> d_doff, d_voff, d_cells, d_vcells;
@@ -1294,7 +1324,7 @@ struct poa_ws {
     vga_dbuf<unsigned long long> d_next;
     vga_hbuf<poa_prob> h_probs;
     vga_hbuf<uint4> h_ntab;
-    vga_hbuf<uint32_t> h_seq32, h_preds, h_sink, h_orow, h_row, h_nops;
+    vga_hbuf<uint32_t> h_seq32, h_preds, h_sink, h_orow, h_row, h_nops, h_maxw;
     vga_hbuf<uint8_t> h_ops;
     vga_hbuf<int32_t> h_score, h_status;
     vga_hbuf<uint64_t> h_cells, h_vcells;
@@ -1358,7 +1388,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         int g1b = 0, g2b = 0;
         while ((1 << g1b) <= params->gap_open1 + params->gap_ext1) g1b++;
         while ((1 << g2b) <= params->gap_open2 + params->gap_ext2) g2b++;
-        const size_t need = g1b + g2b <= 8 ? poa_pk_lds_bytes(lds_cols_all, 128) : poa_lds_bytes(lds_cols_all, 128);
+        const size_t need = g1b + g2b <= 8 ? poa_pk_lds_bytes(lds_cols_all, lds_cols_all, 128) : poa_lds_bytes(lds_cols_all, 128);
         if (need > 160 * 1024 - 256)
             return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query of %u bases does not fit the LDS-resident POA kernel (limit ~35 kbp, ~22 kbp with large gap penalties)", max_q);
     }
@@ -1398,7 +1428,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     POA_CHECK(W.h_probs.reserve(n)); POA_CHECK(W.h_ntab.reserve(tot_nodes)); POA_CHECK(W.h_seq32.reserve(tot_seq / 4 + 1));
     POA_CHECK(W.h_preds.reserve(tot_preds + 1)); POA_CHECK(W.h_sink.reserve(tot_sink + 1)); POA_CHECK(W.h_q.reserve(tot_q + 1));
     POA_CHECK(W.h_ops.reserve(tot_ops)); POA_CHECK(W.h_orow.reserve(tot_ops)); POA_CHECK(W.h_row.reserve(n));
-    POA_CHECK(W.h_nops.reserve(n)); POA_CHECK(W.h_score.reserve(n)); POA_CHECK(W.h_status.reserve(n));
+    POA_CHECK(W.h_nops.reserve(n)); POA_CHECK(W.h_maxw.reserve(n)); POA_CHECK(W.d_maxw.reserve(n)); POA_CHECK(W.h_score.reserve(n)); POA_CHECK(W.h_status.reserve(n));
     POA_CHECK(W.h_cells.reserve(n)); POA_CHECK(W.h_vcells.reserve(n)); POA_CHECK(W.h_next.reserve(1));
     POA_CHECK(W.d_probs.reserve(n)); POA_CHECK(W.d_ntab.reserve(tot_nodes)); POA_CHECK(W.d_seq32.reserve(tot_seq / 4 + 1));
     POA_CHECK(W.d_preds.reserve(tot_preds + 1)); POA_CHECK(W.d_sink.reserve(tot_sink + 1)); POA_CHECK(W.d_q.reserve(tot_q + 1));
@@ -1422,17 +1452,18 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     tr.mark("fill staging (host threads)");
 
     // ---- pool sizing and the launch order (longest estimated problem first, so stragglers start early)
-    auto est_bytes = [&](uint64_t p) -> double {
+    // band width estimate of a problem: 2w+1 plus the distance between the band's diagonal and the row maxima, which
+    // is about the difference between the longest source-sink path and the query length
+    auto est_width = [&](uint64_t p) -> double {
         const poa_prep &g = G[p];
         const double w = params->wb < 0 ? (double)g.qlen : (double)params->wb + (double)(uint64_t)(params->wf * (double)g.qlen);
         double excess = (double)g.longest - (double)g.qlen;
         if (excess < 0) excess = -excess;
-        const double width = std::min((double)g.qlen + 1.0, 2.0 * w + 1.0 + excess + 64.0);
-        return (double)g.N * width * 2.6;
+        return std::min((double)g.qlen + 1.0, 2.0 * w + 1.0 + excess + 64.0);
     };
-    std::vector<double> est(n);
+    std::vector<double> est(n), estw(n);
     std::vector<uint32_t> order(n);
-    for (uint64_t p = 0; p < n; p++) { est[p] = est_bytes(p); order[p] = (uint32_t)p; }
+    for (uint64_t p = 0; p < n; p++) { estw[p] = est_width(p); est[p] = (double)G[p].N * estw[p] * 2.6; order[p] = (uint32_t)p; }
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return est[a] > est[b]; });
     {
         // the traceback output of a sub-batch must be one contiguous slice: number it in launch order
@@ -1479,7 +1510,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     struct sub_t { uint64_t i0, i1; double raw_est; };
     hipError_t launch_err = hipSuccess;
     // enqueue DP + traceback + result copies of the sub-batch starting at launch position i0
-    auto launch = [&](uint64_t i0) -> sub_t {
+    auto launch = [&](uint64_t i0, bool full_window) -> sub_t {
         const double budget = (double)W.pool_size * 0.92;
         double used_est = 0, raw_est = 0;
         uint64_t i1 = i0;
@@ -1496,52 +1527,86 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         int t_dp = vga_timer_begin(ctx, "poa_band_dp", 0);
         {
             uint32_t mq = 0;
-            for (uint64_t i = i0; i < i1; i++) mq = std::max(mq, G[order[i]].qlen);
+            double mw = 0;
+            for (uint64_t i = i0; i < i1; i++) { mq = std::max(mq, G[order[i]].qlen); mw = std::max(mw, estw[order[i]]); }
             const uint32_t lds_cols = poa_lds_cols(mq);
-            // VGA_POA_KERNEL (testing): "unpacked" selects k_poa_dp_lds, "128" / "256" / "512" pin the workgroup size
+            // VGA_POA_KERNEL (testing): "unpacked" selects k_poa_dp_lds, "128" / "256" / "512" pin the workgroup size,
+            // "full" keeps every column in LDS; VGA_POA_WINDOW=<power of two> pins the LDS column window
             const char *force = getenv("VGA_POA_KERNEL");
             int g1bits = 0, g2bits = 0;
             while ((1 << g1bits) <= P.o1 + P.e1) g1bits++;
             while ((1 << g2bits) <= P.o2 + P.e2) g2bits++;
             const bool packed = g1bits + g2bits <= 8 && !(force && strstr(force, "unpacked"));
             packed_all = packed_all && packed;
+            // LDS column window (packed kernel): 4096 columns keep almost every row of a 10 kbp read resident (its widest
+            // rows, a few per cent, take the HBM detour described in the kernel) and let seven workgroups share a CU
+            // instead of three.  Queries that fit a smaller array anyway keep every column.
+            uint32_t hg_cols = lds_cols, win_mask = 0xFFFFFFFFu;
+            if (packed && !full_window && !(force && strstr(force, "full"))) {
+                uint32_t want = 4096;
+                const char *ew = getenv("VGA_POA_WINDOW");
+                if (ew) want = (uint32_t)strtoul(ew, nullptr, 10);
+                if (want >= 16 && (want & (want - 1)) == 0 && want < lds_cols) { hg_cols = want; win_mask = want - 1; }
+            }
+            // workgroup size: a row of the widest band should take about two steps, and the launch should still fill
+            // the GPU (blocks per CU: LDS and 28 waves)
             int nt = mq >= 3072 ? 512 : (mq >= 768 ? 256 : 128);
+            if (packed) {
+                // as many workgroups per CU as the LDS allows, sized so that together they fill the 28 wave slots
+                auto by_lds = [&](int t) { return std::max<size_t>(1, (160 * 1024) / (poa_pk_lds_bytes(hg_cols, lds_cols, t) + 256)); };
+                const size_t blocks = std::min<size_t>(by_lds(128), 14);
+                nt = 64 * (int)std::min<size_t>(8, std::max<size_t>(2, 28 / blocks));
+                // a launch that cannot fill the GPU with that many workgroups per CU uses wider ones
+                while (nt < 512 && (size_t)nb < std::min<size_t>(by_lds(nt), (size_t)(28 / (nt / 64))) * (size_t)ctx->n_cu) nt += 64;
+                const char *ent = getenv("VGA_POA_NT");
+                if (ent) nt = atoi(ent);
+                if (nt < 128 || nt > 512 || nt % 64) nt = 512;
+            }
             if (force) {
                 if (strstr(force, "128")) nt = 128;
                 else if (strstr(force, "256")) nt = 256;
                 else if (strstr(force, "512")) nt = 512;
             }
-            auto lds_of = [&](int t) { return packed ? poa_pk_lds_bytes(lds_cols, t) : poa_lds_bytes(lds_cols, t); };
-            while (nt > 128 && lds_of(nt) > 160 * 1024 - 256) nt /= 2;
+            auto lds_of = [&](int t) { return packed ? poa_pk_lds_bytes(hg_cols, lds_cols, t) : poa_lds_bytes(lds_cols, t); };
+            while (nt > 128 && lds_of(nt) > 160 * 1024 - 256) nt = packed ? nt - 64 : nt / 2;
             const size_t lds = lds_of(nt);
+            if (tr.on)
+                fprintf(stderr, "[vga-trace] poa: launch %u problems, NT %d, window %u of %u columns, widest estimate %.0f, LDS %zu B\n",
+                        nb, nt, hg_cols, lds_cols, mw, lds);
 #define POA_ARGS W.d_probs.p + i0, W.d_q.p, W.d_ntab.p, W.d_seq32.p, W.d_preds.p, W.d_sink.p, P, W.d_beg.p, W.d_end.p, W.d_doff.p,   \
                  W.d_voff.p, W.d_lmax.p, W.d_rmax.p, W.d_info.p, W.pool, W.d_next.p, W.pool_size, W.d_score.p + i0, W.d_row.p + i0, \
                  W.d_status.p + i0, W.d_cells.p + i0, W.d_vcells.p + i0, lds_cols
+#define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, W.d_maxw.p + i0, g1bits
             if (packed) {
                 if (getenv("VGA_POA_STAMPS") && nt == 512) {
                     // diagnostic: per-segment cycle shares of the first 64 workgroups (tid 0's wave), printed to stderr
                     static unsigned long long *d_st = nullptr;
-                    if (!d_st) chk(hipMalloc((void **)&d_st, 64 * 6 * 8));
-                    chk(hipMemsetAsync(d_st, 0, 64 * 6 * 8, st));
+                    if (!d_st) chk(hipMalloc((void **)&d_st, 2 * 64 * 8 * 8));
+                    chk(hipMemsetAsync(d_st, 0, 2 * 64 * 8 * 8, st));
                     chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL((k_poa_dp_pk<512, true>), dim3(nb), dim3(512), lds, st, POA_ARGS, g1bits, d_st);
-                    unsigned long long h_st[64 * 6];
+                    hipLaunchKernelGGL((k_poa_dp_pk<512, true>), dim3(nb), dim3(512), lds, st, POA_PK_ARGS, d_st);
+                    unsigned long long h_st[2 * 64 * 8];
                     chk(hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, st));
                     chk(hipStreamSynchronize(st));
-                    unsigned long long sum[6] = {0, 0, 0, 0, 0, 0}, tot = 0;
-                    for (int b2 = 0; b2 < 64 && b2 < (int)nb; b2++)
-                        for (int s = 0; s < 6; s++) { sum[s] += h_st[b2 * 6 + s]; tot += h_st[b2 * 6 + s]; }
-                    fprintf(stderr, "[vga-stamps] cycles: prologue %llu phase1 %llu scans %llu step-barrier %llu phase2 %llu row-reduce+barrier %llu (total %llu)\n",
-                            sum[0], sum[1], sum[2], sum[3], sum[4], sum[5], tot);
-                } else if (nt == 128) {
-                    chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL((k_poa_dp_pk<128>), dim3(nb), dim3(128), lds, st, POA_ARGS, g1bits);
-                } else if (nt == 256) {
-                    chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL((k_poa_dp_pk<256>), dim3(nb), dim3(256), lds, st, POA_ARGS, g1bits);
+                    for (int wsel = 0; wsel < 2; wsel++) {
+                        unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
+                        for (int b2 = 0; b2 < 64 && b2 < (int)nb; b2++)
+                            for (int s = 0; s < 8; s++) { sum[s] += h_st[wsel * 512 + b2 * 8 + s]; tot += h_st[wsel * 512 + b2 * 8 + s]; }
+                        fprintf(stderr, "[vga-stamps] wave %d cycles: prologue %llu phase1 %llu (interior: loads %llu) scans %llu step-barrier %llu phase2 %llu row-reduce+barrier %llu (total %llu)\n",
+                                wsel * 2, sum[0], sum[1], sum[6], sum[2], sum[3], sum[4], sum[5], tot);
+                    }
                 } else {
-                    chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL((k_poa_dp_pk<512>), dim3(nb), dim3(512), lds, st, POA_ARGS, g1bits);
+#define POA_PK_LAUNCH(T)                                                                                                    \
+    case T:                                                                                                                 \
+        chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+        hipLaunchKernelGGL((k_poa_dp_pk<T>), dim3(nb), dim3(T), lds, st, POA_PK_ARGS);                                     \
+        break;
+                    switch (nt) {
+                        POA_PK_LAUNCH(128) POA_PK_LAUNCH(192) POA_PK_LAUNCH(256) POA_PK_LAUNCH(320)
+                        POA_PK_LAUNCH(384) POA_PK_LAUNCH(448) POA_PK_LAUNCH(512)
+                    default: chk(hipErrorInvalidValue);
+                    }
+#undef POA_PK_LAUNCH
                 }
             } else if (nt == 128) {
                 chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1553,6 +1618,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
                 chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<512, 4>), dim3(nb), dim3(512), lds, st, POA_ARGS);
             }
+#undef POA_PK_ARGS
 #undef POA_ARGS
             chk(hipGetLastError());
         }
@@ -1568,6 +1634,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         chk(hipMemcpyAsync(W.h_next.p, W.d_next.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(W.h_score.p + i0, W.d_score.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(W.h_nops.p + i0, W.d_nops.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(W.h_maxw.p + i0, W.d_maxw.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(W.h_cells.p + i0, W.d_cells.p + i0, nb * 8, hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(W.h_vcells.p + i0, W.d_vcells.p + i0, nb * 8, hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(W.h_ops.p + o0, W.d_ops.p + o0, o1 - o0, hipMemcpyDeviceToHost, st));
@@ -1645,7 +1712,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     // Software pipeline: while the GPU runs sub-batch i+1 the host threads turn sub-batch i's op streams into
     // CIGAR / cs strings.
     int rc_final = VGA_OK;
-    sub_t cur = launch(0);
+    sub_t cur = launch(0, false);
     while (true) {
         POA_CHECK(hipStreamSynchronize(st));
         if (launch_err != hipSuccess)
@@ -1656,16 +1723,35 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         if (pool_fail) {
             if (cur.i1 - cur.i0 == 1 && W.pool_scale >= 4.0) { rc_final = VGA_ERR_POOL; break; }
             W.pool_scale = std::min(8.0, W.pool_scale * 1.7);
-            cur = launch(cur.i0);  // rerun this sub-batch with a more cautious estimate
+            cur = launch(cur.i0, false);  // rerun this sub-batch with a more cautious estimate
             continue;
         }
         if (cur.raw_est > 0) {
             const double ratio = (double)W.h_next.p[0] / cur.raw_est;
             W.pool_scale = std::max(ratio * 1.15, 0.6 * W.pool_scale + 0.4 * ratio * 1.25);
         }
+        if (tr.on) {
+            double worst = 0;
+            uint32_t mx = 0;
+            for (uint64_t i = cur.i0; i < cur.i1; i++) {
+                worst = std::max(worst, (double)W.h_maxw.p[i] / estw[order[i]]);
+                mx = std::max(mx, W.h_maxw.p[i]);
+            }
+            fprintf(stderr, "[vga-trace] poa: sub-batch done, widest row %u columns, worst width / estimate %.3f\n", mx, worst);
+            const char *dump = getenv("VGA_POA_DUMP_WIDTHS");
+            if (dump) {
+                FILE *f = fopen(dump, "a");
+                if (f) {
+                    for (uint64_t i = cur.i0; i < cur.i1; i++)
+                        fprintf(f, "%u %u %d %.0f %u %llu\n", G[order[i]].N, G[order[i]].qlen, G[order[i]].longest, estw[order[i]],
+                                W.h_maxw.p[i], (unsigned long long)W.h_cells.p[i]);
+                    fclose(f);
+                }
+            }
+        }
         const bool have_next = cur.i1 < n;
         sub_t nxt = cur;
-        if (have_next) nxt = launch(cur.i1);
+        if (have_next) { nxt = launch(cur.i1, false); }
         {
             const uint64_t a0 = cur.i0, cnt = cur.i1 - cur.i0;
             parallel_for(cnt, [&](uint64_t t) { post_one(a0 + t); });
