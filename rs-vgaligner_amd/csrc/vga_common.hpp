@@ -42,6 +42,7 @@ struct vga_timer_entry {
     const char *name;
     hipEvent_t e0, e1;
     uint64_t bytes;
+    hipStream_t stream;  // the stream both events are recorded on
 };
 
 struct vga_ctx {
@@ -166,7 +167,7 @@ void vga_parallel_for(uint64_t n, F f)
 
 // event timing helpers (vga_ctx.hip)
 void vga_timers_reset(vga_ctx *ctx);
-int vga_timer_begin(vga_ctx *ctx, const char *name, uint64_t bytes);  // returns timer index
+int vga_timer_begin(vga_ctx *ctx, const char *name, uint64_t bytes, hipStream_t stream = nullptr);  // returns timer index (stream: default ctx->stream)
 void vga_timer_end(vga_ctx *ctx, int idx);
 void vga_timers_collect(vga_ctx *ctx);  // requires the stream to be synchronised
 float vga_timer_sum(const vga_ctx *ctx, const char *prefix);

@@ -108,14 +108,15 @@ void vga_timers_reset(vga_ctx *ctx)
     ctx->events_used = 0;
 }
 
-int vga_timer_begin(vga_ctx *ctx, const char *name, uint64_t bytes)
+int vga_timer_begin(vga_ctx *ctx, const char *name, uint64_t bytes, hipStream_t stream)
 {
     vga_timer_entry t;
     t.name = name;
     t.bytes = bytes;
+    t.stream = stream ? stream : ctx->stream;
     t.e0 = vga_event_get(ctx);
     t.e1 = vga_event_get(ctx);
-    if (t.e0) (void)hipEventRecord(t.e0, ctx->stream);
+    if (t.e0) (void)hipEventRecord(t.e0, t.stream);
     ctx->timers.push_back(t);
     return (int)ctx->timers.size() - 1;
 }
@@ -123,7 +124,7 @@ int vga_timer_begin(vga_ctx *ctx, const char *name, uint64_t bytes)
 void vga_timer_end(vga_ctx *ctx, int idx)
 {
     if (idx < 0 || (size_t)idx >= ctx->timers.size()) return;
-    if (ctx->timers[idx].e1) (void)hipEventRecord(ctx->timers[idx].e1, ctx->stream);
+    if (ctx->timers[idx].e1) (void)hipEventRecord(ctx->timers[idx].e1, ctx->timers[idx].stream);
 }
 
 void vga_timers_collect(vga_ctx *ctx)

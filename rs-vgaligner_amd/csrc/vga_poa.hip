@@ -55,6 +55,22 @@ struct poa_prob {
     uint32_t pad;
 };
 
+struct poa_row {          // per DP row, 40 B
+    int32_t beg, end;     // band
+    uint64_t doff, voff;  // direction row / value row in the pool
+    uint32_t pred, npred; // predecessor row or predecessor-list slice; npred != 0 only on the first row of a node
+    int32_t lmax, rmax;   // leftmost / rightmost column of the row maximum
+};
+
+struct poa_out {          // per problem, 40 B
+    int32_t score;
+    uint32_t row;         // sink predecessor the traceback starts from
+    int32_t status;
+    uint32_t maxw;        // widest row (storage columns)
+    uint64_t cells, vcells;
+    uint32_t nops, pad;
+};
+
 struct poa_dev_params {
     int32_t match, mismatch, o1, e1, o2, e2, banded;
 };
@@ -102,11 +118,8 @@ template <int NT, int CPT, bool STAMP = false>
 __global__ __launch_bounds__(NT) void k_poa_dp_lds(
     const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
     const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
-    poa_dev_params P, int32_t *row_beg, int32_t *row_end, uint64_t *row_doff, uint64_t *row_voff, int32_t *row_lmax,
-    int32_t *row_rmax, uint2 *row_info,
-    uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size, int32_t *__restrict__ out_score,
-    uint32_t *__restrict__ out_row, int32_t *__restrict__ out_status, uint64_t *__restrict__ out_cells,
-    uint64_t *__restrict__ out_vcells, uint32_t lds_cols, unsigned long long *stamps = nullptr)
+    poa_dev_params P, poa_row *rows, uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size,
+    poa_out *__restrict__ outs, uint32_t lds_cols, unsigned long long *stamps = nullptr)
 {
     static_assert(CPT == 4, "row storage is 4-column aligned");
     constexpr int NW = NT / 64;
@@ -133,13 +146,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
     // Plain (non-volatile) accesses: a volatile store makes hipcc wait vmcnt(0) first, i.e. for every direction-byte
     // store still in flight.  Cross-wave visibility of these arrays is only needed by "far" rows and by the sink
     // evaluation, both of which sit behind a full __syncthreads().
-    int32_t *vbeg = row_beg + pb.row0;
-    int32_t *vend = row_end + pb.row0;
-    uint64_t *vvoff = row_voff + pb.row0;
-    int32_t *vlmax = row_lmax + pb.row0;
-    int32_t *vrmax = row_rmax + pb.row0;
-    uint64_t *gdoff = row_doff + pb.row0;
-    uint2 *ginfo = row_info + pb.row0;
+    poa_row *R = rows + pb.row0;
 
     const int o1 = P.o1, e1 = P.e1, o2 = P.o2, e2 = P.e2;
     const int bw = (int)pb.w;
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
                 const uint32_t p = np == 1 ? ps : plist[ps + t];
                 int lm, rm;
                 if (p == r - 1) { lm = prev_lmax + 1; rm = prev_rmax + 1; }
-                else { lm = vlmax[p] + 1; rm = vrmax[p] + 1; }
+                else { lm = R[p].lmax + 1; rm = R[p].rmax + 1; }
                 mpl = lm < mpl ? lm : mpl;
                 mpr = rm > mpr ? rm : mpr;
             }
@@ -248,11 +255,9 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
         uint64_t voff = 0;
         if (last) { voff = alloc(vcur, vendp, 6ull * (uint64_t)W); if (failed) break; }
         if (tid == 0) {
-            vbeg[r] = beg;
-            vend[r] = end;
-            gdoff[r] = doff;
-            vvoff[r] = voff;
-            ginfo[r] = make_uint2(ps, first ? (uint32_t)np : 0u);
+            R[r].beg = beg; R[r].end = end;
+            R[r].doff = doff; R[r].voff = voff;
+            R[r].pred = ps; R[r].npred = first ? (uint32_t)np : 0u;
         }
         int32_t *Hrow = (int32_t *)(pool + voff);                       // value row: int32 H[W] then uint16 D[W]
         uint16_t *Drow = (uint16_t *)(pool + voff + 4ull * (uint64_t)W);
@@ -352,8 +357,8 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
                             hm0 = POA_NEG;
                             if (j0 >= 1) hm0 = (tid == 0 && c0 > 0) ? edgeH[buf ^ 1] : Hs[j0 - 1];
                         } else {
-                            bp = vbeg[p]; ep = vend[p];
-                            const uint64_t pv = vvoff[p];
+                            bp = R[p].beg; ep = R[p].end;
+                            const uint64_t pv = R[p].voff;
                             const int balp = bp & ~3;
                             const int Wp = (ep - balp + 1 + 3) & ~3;
                             const int32_t *Hp = (const int32_t *)(pool + pv);
@@ -534,72 +539,73 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
         // uniform values: keep them in scalar registers so the next row's band arithmetic runs on the scalar unit
         lpos = __builtin_amdgcn_readfirstlane(lpos);
         rpos = __builtin_amdgcn_readfirstlane(rpos);
-        if (tid == 0) { vlmax[r] = lpos; vrmax[r] = rpos; }
+        if (tid == 0) { R[r].lmax = lpos; R[r].rmax = rpos; }
         prev_beg = beg; prev_end = end; prev_lmax = lpos; prev_rmax = rpos;
         stamp(5);  // row reduce + row barrier
     }
     }
     __syncthreads();
     if (tid == 0) {
-        out_cells[blockIdx.x] = cells;
-        out_vcells[blockIdx.x] = vcells;
+        poa_out &O = outs[blockIdx.x];
+        O.cells = cells;
+        O.vcells = vcells;
+        O.maxw = 0;
         if constexpr (STAMP) {
             if (stamps && blockIdx.x < 64)
                 for (int s = 0; s < 6; s++) stamps[blockIdx.x * 6 + s] = tacc[s];
             if (stamps && blockIdx.x == 0) { stamps[384] = n_far; stamps[385] = n_multi; stamps[386] = n_rows; stamps[387] = n_steps; }
         }
         if (failed) {
-            out_status[blockIdx.x] = POA_ST_POOL;
-            out_score[blockIdx.x] = POA_NEG;
-            out_row[blockIdx.x] = 0;
+            O.status = POA_ST_POOL;
+            O.score = POA_NEG;
+            O.row = 0;
         } else {
             int bestv = INT32_MIN;
             uint32_t brow = 0;
             bool have = false;
             for (uint32_t t = 0; t < pb.n_sink; t++) {
                 const uint32_t p = sink_preds[pb.sink0 + t];
-                const int bp = vbeg[p], ep = vend[p];
+                const int bp = R[p].beg, ep = R[p].end;
                 int val = POA_NEG;
-                if (qlen >= bp && qlen <= ep) val = ((const int32_t *)(pool + vvoff[p]))[qlen - (bp & ~3)];
+                if (qlen >= bp && qlen <= ep) val = ((const int32_t *)(pool + R[p].voff))[qlen - (bp & ~3)];
                 if (!have || val > bestv) { bestv = val; brow = p; have = true; }
             }
-            out_score[blockIdx.x] = bestv;
-            out_row[blockIdx.x] = brow;
-            out_status[blockIdx.x] = (have && bestv > POA_NEG / 2) ? POA_ST_OK : POA_ST_NOALN;
+            O.score = bestv;
+            O.row = brow;
+            O.status = (have && bestv > POA_NEG / 2) ? POA_ST_OK : POA_ST_NOALN;
         }
     }
 }
 
 // K4b: one lane per problem.  ops are written in reverse (sink -> source) order.
 __global__ __launch_bounds__(64) void k_poa_traceback(
-    uint32_t n, const poa_prob *__restrict__ probs, const uint2 *__restrict__ row_info,
-    const uint32_t *__restrict__ preds, const int32_t *__restrict__ row_beg, const int32_t *__restrict__ row_end,
-    const uint64_t *__restrict__ row_doff, const uint8_t *__restrict__ pool, const uint32_t *__restrict__ out_row,
-    int32_t *__restrict__ out_status, uint8_t *__restrict__ ops, uint32_t *__restrict__ orow,
-    uint32_t *__restrict__ out_nops)
+    uint32_t n, const poa_prob *__restrict__ probs, const poa_row *__restrict__ rows,
+    const uint32_t *__restrict__ preds, const uint8_t *__restrict__ pool, poa_out *__restrict__ outs,
+    uint8_t *__restrict__ ops, uint32_t *__restrict__ orow)
 {
     const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= n) return;
-    out_nops[pi] = 0;
-    if (out_status[pi] != POA_ST_OK) return;
+    outs[pi].nops = 0;
+    if (outs[pi].status != POA_ST_OK) return;
     const poa_prob pb = probs[pi];
     const uint64_t cap = (uint64_t)pb.N + pb.qlen + 2;
     uint8_t *po = ops + pb.ops0;
     uint32_t *pr = orow + pb.ops0;
-    uint32_t i = out_row[pi];
+    uint32_t i = outs[pi].row;
     int j = (int)pb.qlen;
     int st = 0;  // 0 H, 1 E1, 2 E2, 3 F1, 4 F2, 5 Ht
     uint64_t nops = 0;
     bool bad = false;
     while (i > 0 && !bad) {
         const uint64_t ri = pb.row0 + i;
-        const uint2 inf = row_info[ri];  // {pred_start, npred if this row starts a node else 0}
+        const poa_row rw = rows[ri];
+        const uint2 inf = make_uint2(rw.pred, rw.npred);  // {pred_start, npred if this row starts a node else 0}
         const bool first = inf.y != 0;
         const int np = first ? (int)inf.y : 1;
-        const int beg = row_beg[ri], end = row_end[ri];
+        const int beg = rw.beg, end = rw.end;
         const int bal = beg & ~3;
         const uint64_t W = (uint64_t)((end - bal + 1 + 3) & ~3);
-        const uint64_t doff = row_doff[ri];
+        const uint64_t doff = rw.doff;
         if (j < beg || j > end) { bad = true; break; }
         const uint64_t c = (uint64_t)(j - bal);
         const int code = pool[doff + c];
@@ -636,8 +642,8 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
         po[nops] = 1; pr[nops] = 0; nops++;
         j--;
     }
-    if (bad) { out_status[pi] = POA_ST_TRACE; nops = 0; }
-    out_nops[pi] = (uint32_t)nops;
+    if (bad) { outs[pi].status = POA_ST_TRACE; nops = 0; }
+    outs[pi].nops = (uint32_t)nops;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -656,11 +662,8 @@ template <int NT, bool STAMP = false>
 __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
     const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
-    poa_dev_params P, int32_t *row_beg, int32_t *row_end, uint64_t *row_doff, uint64_t *row_voff, int32_t *row_lmax,
-    int32_t *row_rmax, uint2 *row_info, uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size,
-    int32_t *__restrict__ out_score, uint32_t *__restrict__ out_row, int32_t *__restrict__ out_status,
-    uint64_t *__restrict__ out_cells, uint64_t *__restrict__ out_vcells, uint32_t lds_cols, uint32_t hg_cols, uint32_t win_mask,
-    uint32_t *__restrict__ out_maxw, int g1bits,
+    poa_dev_params P, poa_row *rows, uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size,
+    poa_out *__restrict__ outs, uint32_t lds_cols, uint32_t hg_cols, uint32_t win_mask, int g1bits,
     unsigned long long *stamps = nullptr)
 {
     constexpr int CPT = 4;
@@ -683,13 +686,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     const char *query = queries + pb.q0;
     const uint4 *ntab = node_tab + pb.node0;
     const uint32_t *plist = preds + pb.pred0;
-    int32_t *vbeg = row_beg + pb.row0;
-    int32_t *vend = row_end + pb.row0;
-    uint64_t *vvoff = row_voff + pb.row0;
-    int32_t *vlmax = row_lmax + pb.row0;
-    int32_t *vrmax = row_rmax + pb.row0;
-    uint64_t *gdoff = row_doff + pb.row0;
-    uint2 *ginfo = row_info + pb.row0;
+    poa_row *R = rows + pb.row0;
 
     const int o1 = P.o1, e1 = P.e1, o2 = P.o2, e2 = P.e2;
     const int oe1 = o1 + e1, oe2 = o2 + e2;
@@ -749,11 +746,14 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     // the branch-free interior path assumes every query base scores match or mismatch
     const bool q_plain = __syncthreads_or(non_acgt) == 0;
 
+    // two scratch value rows for rows wider than the LDS window (they only feed the row directly below)
+    uint64_t wide_scratch = 0;
+    if (win_mask != 0xFFFFFFFFu) wide_scratch = alloc(vcur, vendp, 8ull * lds_cols);
     int prev_beg = 0, prev_end = -1, prev_lmax = 0, prev_rmax = 0;
     uint64_t cells = 0, vcells = 0;
     uint32_t seq_word = 0, seq_word_idx = 0xFFFFFFFFu;
 
-    for (uint32_t v = 0; v < pb.n_nodes && !failed; v++) {
+    for (uint32_t v = 0; v < pb.n_nodes && !failed; v++) {  // (a failed scratch allocation ends here as well)
     const uint4 nt = ntab[v];
     const uint32_t nlen = nt.y & 0xFFFFFFu;
     for (uint32_t tn = 0; tn < nlen && !failed; tn++) {
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                 const uint32_t p = np == 1 ? ps : plist[ps + t];
                 int lm, rm;
                 if (p == r - 1) { lm = prev_lmax + 1; rm = prev_rmax + 1; }
-                else { lm = vlmax[p] + 1; rm = vrmax[p] + 1; }
+                else { lm = R[p].lmax + 1; rm = R[p].rmax + 1; }
                 mpl = lm < mpl ? lm : mpl;
                 mpr = rm > mpr ? rm : mpr;
             }
@@ -813,13 +813,12 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
         const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u));
         if (failed) break;
         uint64_t voff = 0;
-        if (keep) { voff = alloc(vcur, vendp, 4ull * (uint64_t)W); if (failed) break; }
+        if (last) { voff = alloc(vcur, vendp, 4ull * (uint64_t)W); if (failed) break; }
+        else if (wide) voff = wide_scratch + (r & 1u) * 4ull * lds_cols;
         if (tid == 0) {
-            vbeg[r] = beg;
-            vend[r] = end;
-            gdoff[r] = doff;
-            vvoff[r] = voff;
-            ginfo[r] = make_uint2(ps, first ? (uint32_t)np : 0u);
+            R[r].beg = beg; R[r].end = end;
+            R[r].doff = doff; R[r].voff = voff;
+            R[r].pred = ps; R[r].npred = first ? (uint32_t)np : 0u;
         }
         int32_t *Vrow = (int32_t *)(pool + voff);  // value row: packed words
         uint8_t *drow = pool + doff;
@@ -837,9 +836,9 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
         if (single && !sp_near) {
             // uniform values of a far row: read them into scalar registers right here, so that their s_waitcnt vmcnt
             // stays inside this branch (in shared code it would make every row wait for its predecessors' stores)
-            pbeg = __builtin_amdgcn_readfirstlane(vbeg[sp]);
-            pend = __builtin_amdgcn_readfirstlane(vend[sp]);
-            const uint64_t vo = vvoff[sp];
+            pbeg = __builtin_amdgcn_readfirstlane(R[sp].beg);
+            pend = __builtin_amdgcn_readfirstlane(R[sp].end);
+            const uint64_t vo = R[sp].voff;
             const uint64_t vos = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(vo >> 32)) << 32) |
                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vo);
             Vp = (const int32_t *)(pool + vos);
@@ -985,9 +984,9 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                             wm0 = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : (jm1 & win_mask)];
                             asm volatile("" : "+v"(wm0));
                         } else {
-                            bp = __builtin_amdgcn_readfirstlane(vbeg[p]);
-                            ep = __builtin_amdgcn_readfirstlane(vend[p]);
-                            const uint64_t vo = vvoff[p];
+                            bp = __builtin_amdgcn_readfirstlane(R[p].beg);
+                            ep = __builtin_amdgcn_readfirstlane(R[p].end);
+                            const uint64_t vo = R[p].voff;
                             const uint64_t vos = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(vo >> 32)) << 32) |
                                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vo);
                             const int32_t *Vq = (const int32_t *)(pool + vos);
@@ -1183,7 +1182,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
             lpos = -__builtin_amdgcn_readlane(lm, NW - 1);
             rpos = __builtin_amdgcn_readlane(rm, NW - 1);
         }
-        if (tid == 0) { vlmax[r] = lpos; vrmax[r] = rpos; }
+        if (tid == 0) { R[r].lmax = lpos; R[r].rmax = rpos; }
         prev_beg = beg; prev_end = end; prev_lmax = lpos; prev_rmax = rpos;
         prev_lds = !wide;
         stamp(5);
@@ -1196,27 +1195,28 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
             for (int s = 0; s < 8; s++) stamps[(tid ? 64 * 8 : 0) + blockIdx.x * 8 + s] = tacc[s];
     }
     if (tid == 0) {
-        out_cells[blockIdx.x] = cells;
-        out_vcells[blockIdx.x] = vcells;
-        out_maxw[blockIdx.x] = (uint32_t)maxw;
+        poa_out &O = outs[blockIdx.x];
+        O.cells = cells;
+        O.vcells = vcells;
+        O.maxw = (uint32_t)maxw;
         if (failed) {
-            out_status[blockIdx.x] = POA_ST_POOL;
-            out_score[blockIdx.x] = POA_NEG;
-            out_row[blockIdx.x] = 0;
+            O.status = POA_ST_POOL;
+            O.score = POA_NEG;
+            O.row = 0;
         } else {
             int bestv = INT32_MIN;
             uint32_t brow = 0;
             bool have = false;
             for (uint32_t t = 0; t < pb.n_sink; t++) {
                 const uint32_t p = sink_preds[pb.sink0 + t];
-                const int bp = vbeg[p], ep = vend[p];
+                const int bp = R[p].beg, ep = R[p].end;
                 int val = POA_NEG;
-                if (qlen >= bp && qlen <= ep) val = ((const int32_t *)(pool + vvoff[p]))[qlen - (bp & ~3)] >> 8;
+                if (qlen >= bp && qlen <= ep) val = ((const int32_t *)(pool + R[p].voff))[qlen - (bp & ~3)] >> 8;
                 if (!have || val > bestv) { bestv = val; brow = p; have = true; }
             }
-            out_score[blockIdx.x] = bestv;
-            out_row[blockIdx.x] = brow;
-            out_status[blockIdx.x] = (have && bestv > POA_NEG / 2) ? POA_ST_OK : POA_ST_NOALN;
+            O.score = bestv;
+            O.row = brow;
+            O.status = (have && bestv > POA_NEG / 2) ? POA_ST_OK : POA_ST_NOALN;
         }
     }
 }
@@ -1315,25 +1315,31 @@ void poa_prepare(const poa_view &v, poa_prep &g)
 struct poa_ws {
     vga_dbuf<poa_prob> d_probs;
     vga_dbuf<uint4> d_ntab;
-    vga_dbuf<uint32_t> d_seq32, d_preds, d_sink, d_row, d_orow, d_nops, d_maxw;
+    vga_dbuf<uint32_t> d_seq32, d_preds, d_sink, d_orow;
     vga_dbuf<uint8_t> d_ops;
-    vga_dbuf<int32_t> d_beg, d_end, d_lmax, d_rmax, d_score, d_status;
-    vga_dbuf<uint64_t> d_doff, d_voff, d_cells, d_vcells;
-    vga_dbuf<uint2> d_info;
+    vga_dbuf<poa_row> d_rows;
+    vga_dbuf<poa_out> d_outs;
     vga_dbuf<char> d_q;
     vga_dbuf<unsigned long long> d_next;
     vga_hbuf<poa_prob> h_probs;
     vga_hbuf<uint4> h_ntab;
-    vga_hbuf<uint32_t> h_seq32, h_preds, h_sink, h_orow, h_row, h_nops, h_maxw;
+    vga_hbuf<uint32_t> h_seq32, h_preds, h_sink, h_orow;
     vga_hbuf<uint8_t> h_ops;
-    vga_hbuf<int32_t> h_score, h_status;
-    vga_hbuf<uint64_t> h_cells, h_vcells;
+    vga_hbuf<poa_out> h_outs;
     vga_hbuf<char> h_q;
     vga_hbuf<unsigned long long> h_next;
     uint8_t *pool = nullptr;
     uint64_t pool_size = 0;
-    double pool_scale = 0.30;  // measured pool bytes / estimated bytes, adapted after every sub-batch
-    ~poa_ws() { if (pool) (void)hipFree(pool); }
+    hipStream_t st2 = nullptr;   // sub-batches alternate between the context's stream and this one
+    hipEvent_t ev_up = nullptr, ev_join = nullptr;
+    double pool_scale = 1.0;   // measured pool bytes / estimated bytes, adapted after every sub-batch
+    ~poa_ws()
+    {
+        if (pool) (void)hipFree(pool);
+        if (st2) (void)hipStreamDestroy(st2);
+        if (ev_up) (void)hipEventDestroy(ev_up);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+    }
 };
 
 template <typename T>
@@ -1427,17 +1433,12 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     } while (0)
     POA_CHECK(W.h_probs.reserve(n)); POA_CHECK(W.h_ntab.reserve(tot_nodes)); POA_CHECK(W.h_seq32.reserve(tot_seq / 4 + 1));
     POA_CHECK(W.h_preds.reserve(tot_preds + 1)); POA_CHECK(W.h_sink.reserve(tot_sink + 1)); POA_CHECK(W.h_q.reserve(tot_q + 1));
-    POA_CHECK(W.h_ops.reserve(tot_ops)); POA_CHECK(W.h_orow.reserve(tot_ops)); POA_CHECK(W.h_row.reserve(n));
-    POA_CHECK(W.h_nops.reserve(n)); POA_CHECK(W.h_maxw.reserve(n)); POA_CHECK(W.d_maxw.reserve(n)); POA_CHECK(W.h_score.reserve(n)); POA_CHECK(W.h_status.reserve(n));
-    POA_CHECK(W.h_cells.reserve(n)); POA_CHECK(W.h_vcells.reserve(n)); POA_CHECK(W.h_next.reserve(1));
+    POA_CHECK(W.h_ops.reserve(tot_ops)); POA_CHECK(W.h_orow.reserve(tot_ops)); POA_CHECK(W.h_outs.reserve(n));
+    POA_CHECK(W.h_next.reserve(2));
     POA_CHECK(W.d_probs.reserve(n)); POA_CHECK(W.d_ntab.reserve(tot_nodes)); POA_CHECK(W.d_seq32.reserve(tot_seq / 4 + 1));
     POA_CHECK(W.d_preds.reserve(tot_preds + 1)); POA_CHECK(W.d_sink.reserve(tot_sink + 1)); POA_CHECK(W.d_q.reserve(tot_q + 1));
-    POA_CHECK(W.d_beg.reserve(tot_rows)); POA_CHECK(W.d_end.reserve(tot_rows)); POA_CHECK(W.d_doff.reserve(tot_rows));
-    POA_CHECK(W.d_voff.reserve(tot_rows)); POA_CHECK(W.d_lmax.reserve(tot_rows)); POA_CHECK(W.d_rmax.reserve(tot_rows));
-    POA_CHECK(W.d_info.reserve(tot_rows));
-    POA_CHECK(W.d_score.reserve(n)); POA_CHECK(W.d_status.reserve(n)); POA_CHECK(W.d_row.reserve(n)); POA_CHECK(W.d_cells.reserve(n));
-    POA_CHECK(W.d_vcells.reserve(n)); POA_CHECK(W.d_ops.reserve(tot_ops)); POA_CHECK(W.d_orow.reserve(tot_ops));
-    POA_CHECK(W.d_nops.reserve(n)); POA_CHECK(W.d_next.reserve(1));
+    POA_CHECK(W.d_rows.reserve(tot_rows)); POA_CHECK(W.d_outs.reserve(n));
+    POA_CHECK(W.d_ops.reserve(tot_ops)); POA_CHECK(W.d_orow.reserve(tot_ops)); POA_CHECK(W.d_next.reserve(2));
     tr.mark("reserve");
     parallel_for(n, [&](uint64_t p) {
         const poa_prob &pb = probs[p];
@@ -1452,18 +1453,20 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     tr.mark("fill staging (host threads)");
 
     // ---- pool sizing and the launch order (longest estimated problem first, so stragglers start early)
-    // band width estimate of a problem: 2w+1 plus the distance between the band's diagonal and the row maxima, which
-    // is about the difference between the longest source-sink path and the query length
+    // Mean band width of a problem.  The band of a row spans from the row maxima to the diagonal qlen - remain, so it
+    // grows with the excess of the longest source-sink path over the query; on 10 kbp reads against DRB1-3123 the mean is
+    // 2w + 1 + 430 + 0.27 * excess (rms error ~25 %).  Only the pool budget and the launch order depend on it, and the
+    // budget scale adapts to the measured footprint after every sub-batch.
     auto est_width = [&](uint64_t p) -> double {
         const poa_prep &g = G[p];
         const double w = params->wb < 0 ? (double)g.qlen : (double)params->wb + (double)(uint64_t)(params->wf * (double)g.qlen);
         double excess = (double)g.longest - (double)g.qlen;
         if (excess < 0) excess = -excess;
-        return std::min((double)g.qlen + 1.0, 2.0 * w + 1.0 + excess + 64.0);
+        return std::min((double)g.qlen + 1.0, 2.0 * w + 1.0 + 430.0 + 0.3 * excess);
     };
     std::vector<double> est(n), estw(n);
     std::vector<uint32_t> order(n);
-    for (uint64_t p = 0; p < n; p++) { estw[p] = est_width(p); est[p] = (double)G[p].N * estw[p] * 2.6; order[p] = (uint32_t)p; }
+    for (uint64_t p = 0; p < n; p++) { estw[p] = est_width(p); est[p] = (double)G[p].N * estw[p] * 2.2; order[p] = (uint32_t)p; }
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return est[a] > est[b]; });
     {
         // the traceback output of a sub-batch must be one contiguous slice: number it in launch order
@@ -1501,20 +1504,35 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     POA_CHECK(hipMemcpyAsync(W.d_sink.p, W.h_sink.p, tot_sink * 4, hipMemcpyHostToDevice, st));
     POA_CHECK(hipMemcpyAsync(W.d_q.p, W.h_q.p, tot_q, hipMemcpyHostToDevice, st));
 
+    // Two sub-batches are in flight at any time, one per stream, each carving from its own half of the pool: while one
+    // sub-batch drains (its last workgroups, then the latency-bound traceback and the copies back) the other one's
+    // workgroups fill the CUs.
+    if (!W.st2) {
+        POA_CHECK(hipStreamCreateWithFlags(&W.st2, hipStreamNonBlocking));
+        POA_CHECK(hipEventCreateWithFlags(&W.ev_up, hipEventDisableTiming));
+        POA_CHECK(hipEventCreateWithFlags(&W.ev_join, hipEventDisableTiming));
+    }
+    POA_CHECK(hipEventRecord(W.ev_up, st));
+    POA_CHECK(hipStreamWaitEvent(W.st2, W.ev_up, 0));
+    hipStream_t sarr[2] = {st, W.st2};
+    const uint64_t half_pool = (W.pool_size / 2) & ~(POA_CHUNK - 1);
+
     poa_dev_params P;
     P.match = params->match; P.mismatch = params->mismatch; P.o1 = params->gap_open1; P.e1 = params->gap_ext1;
     P.o2 = params->gap_open2; P.e2 = params->gap_ext2; P.banded = params->wb >= 0;
 
     bool packed_all = true;  // value rows are 4 B per cell with the packed kernel, 6 B otherwise (byte model)
     int t_total = vga_timer_begin(ctx, "poa_total", 0);
-    struct sub_t { uint64_t i0, i1; double raw_est; };
+    struct sub_t { uint64_t i0, i1; double raw_est; int slot; };
     hipError_t launch_err = hipSuccess;
-    // enqueue DP + traceback + result copies of the sub-batch starting at launch position i0
-    auto launch = [&](uint64_t i0, bool full_window) -> sub_t {
-        const double budget = (double)W.pool_size * 0.92;
+    // enqueue DP + traceback + result copies of a sub-batch that starts at launch position i0 and ends at cap at the latest
+    auto launch = [&](uint64_t i0, uint64_t cap, int slot) -> sub_t {
+        hipStream_t st = sarr[slot];  // shadows the context's stream inside this lambda
+        uint8_t *pool_base = W.pool + (uint64_t)slot * half_pool;
+        const double budget = (double)half_pool * 0.92;
         double used_est = 0, raw_est = 0;
         uint64_t i1 = i0;
-        while (i1 < n) {
+        while (i1 < cap) {
             const double e = est[order[i1]] * W.pool_scale + 3.0 * (double)POA_CHUNK;
             if (i1 > i0 && used_est + e > budget) break;
             used_est += e;
@@ -1523,8 +1541,8 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         }
         const uint32_t nb = (uint32_t)(i1 - i0);
         auto chk = [&](hipError_t e) { if (e != hipSuccess && launch_err == hipSuccess) launch_err = e; };
-        chk(hipMemsetAsync(W.d_next.p, 0, sizeof(unsigned long long), st));
-        int t_dp = vga_timer_begin(ctx, "poa_band_dp", 0);
+        chk(hipMemsetAsync(W.d_next.p + slot, 0, sizeof(unsigned long long), st));
+        int t_dp = vga_timer_begin(ctx, "poa_band_dp", 0, st);
         {
             uint32_t mq = 0;
             double mw = 0;
@@ -1542,7 +1560,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             // rows, a few per cent, take the HBM detour described in the kernel) and let seven workgroups share a CU
             // instead of three.  Queries that fit a smaller array anyway keep every column.
             uint32_t hg_cols = lds_cols, win_mask = 0xFFFFFFFFu;
-            if (packed && !full_window && !(force && strstr(force, "full"))) {
+            if (packed && !(force && strstr(force, "full"))) {
                 uint32_t want = 4096;
                 const char *ew = getenv("VGA_POA_WINDOW");
                 if (ew) want = (uint32_t)strtoul(ew, nullptr, 10);
@@ -1552,12 +1570,16 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             // the GPU (blocks per CU: LDS and 28 waves)
             int nt = mq >= 3072 ? 512 : (mq >= 768 ? 256 : 128);
             if (packed) {
-                // as many workgroups per CU as the LDS allows, sized so that together they fill the 28 wave slots
+                // workgroup size: the one that keeps the most waves resident (LDS and the 28 wave slots of a CU bound the
+                // workgroups per CU; the problems still to be run -- this sub-batch and the ones that will overlap it --
+                // bound how many there are); ties go to the smaller workgroup, whose barriers are cheaper
                 auto by_lds = [&](int t) { return std::max<size_t>(1, (160 * 1024) / (poa_pk_lds_bytes(hg_cols, lds_cols, t) + 256)); };
-                const size_t blocks = std::min<size_t>(by_lds(128), 14);
-                nt = 64 * (int)std::min<size_t>(8, std::max<size_t>(2, 28 / blocks));
-                // a launch that cannot fill the GPU with that many workgroups per CU uses wider ones
-                while (nt < 512 && (size_t)nb < std::min<size_t>(by_lds(nt), (size_t)(28 / (nt / 64))) * (size_t)ctx->n_cu) nt += 64;
+                size_t best_waves = 0;
+                for (int t = 128; t <= 512; t += 64) {
+                    const size_t per_cu = std::min<size_t>(by_lds(t), (size_t)(28 / (t / 64)));
+                    const size_t waves = std::min<size_t>(n - i0, per_cu * (size_t)ctx->n_cu) * (size_t)(t / 64);
+                    if (waves > best_waves) { best_waves = waves; nt = t; }
+                }
                 const char *ent = getenv("VGA_POA_NT");
                 if (ent) nt = atoi(ent);
                 if (nt < 128 || nt > 512 || nt % 64) nt = 512;
@@ -1573,10 +1595,9 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             if (tr.on)
                 fprintf(stderr, "[vga-trace] poa: launch %u problems, NT %d, window %u of %u columns, widest estimate %.0f, LDS %zu B\n",
                         nb, nt, hg_cols, lds_cols, mw, lds);
-#define POA_ARGS W.d_probs.p + i0, W.d_q.p, W.d_ntab.p, W.d_seq32.p, W.d_preds.p, W.d_sink.p, P, W.d_beg.p, W.d_end.p, W.d_doff.p,   \
-                 W.d_voff.p, W.d_lmax.p, W.d_rmax.p, W.d_info.p, W.pool, W.d_next.p, W.pool_size, W.d_score.p + i0, W.d_row.p + i0, \
-                 W.d_status.p + i0, W.d_cells.p + i0, W.d_vcells.p + i0, lds_cols
-#define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, W.d_maxw.p + i0, g1bits
+#define POA_ARGS W.d_probs.p + i0, W.d_q.p, W.d_ntab.p, W.d_seq32.p, W.d_preds.p, W.d_sink.p, P, W.d_rows.p, pool_base,      \
+                 W.d_next.p + slot, half_pool, W.d_outs.p + i0, lds_cols
+#define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, g1bits
             if (packed) {
                 if (getenv("VGA_POA_STAMPS") && nt == 512) {
                     // diagnostic: per-segment cycle shares of the first 64 workgroups (tid 0's wave), printed to stderr
@@ -1623,32 +1644,27 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             chk(hipGetLastError());
         }
         vga_timer_end(ctx, t_dp);
-        int t_tb = vga_timer_begin(ctx, "poa_traceback", 0);
-        hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, W.d_probs.p + i0, W.d_info.p, W.d_preds.p,
-                           W.d_beg.p, W.d_end.p, W.d_doff.p, W.pool, W.d_row.p + i0, W.d_status.p + i0, W.d_ops.p, W.d_orow.p,
-                           W.d_nops.p + i0);
+        int t_tb = vga_timer_begin(ctx, "poa_traceback", 0, st);
+        hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, W.d_probs.p + i0, W.d_rows.p, W.d_preds.p,
+                           pool_base, W.d_outs.p + i0, W.d_ops.p, W.d_orow.p);
         vga_timer_end(ctx, t_tb);
         const uint64_t o0 = probs[order[i0]].ops0;
         const uint64_t o1 = i1 < n ? probs[order[i1]].ops0 : tot_ops;
-        chk(hipMemcpyAsync(W.h_status.p + i0, W.d_status.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
-        chk(hipMemcpyAsync(W.h_next.p, W.d_next.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        chk(hipMemcpyAsync(W.h_score.p + i0, W.d_score.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
-        chk(hipMemcpyAsync(W.h_nops.p + i0, W.d_nops.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
-        chk(hipMemcpyAsync(W.h_maxw.p + i0, W.d_maxw.p + i0, nb * 4, hipMemcpyDeviceToHost, st));
-        chk(hipMemcpyAsync(W.h_cells.p + i0, W.d_cells.p + i0, nb * 8, hipMemcpyDeviceToHost, st));
-        chk(hipMemcpyAsync(W.h_vcells.p + i0, W.d_vcells.p + i0, nb * 8, hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(W.h_outs.p + i0, W.d_outs.p + i0, nb * sizeof(poa_out), hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(W.h_next.p + slot, W.d_next.p + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(W.h_ops.p + o0, W.d_ops.p + o0, o1 - o0, hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(W.h_orow.p + o0, W.d_orow.p + o0, (o1 - o0) * 4, hipMemcpyDeviceToHost, st));
-        return {i0, i1, raw_est};
+        return {i0, i1, raw_est, slot};
     };
     // host: CIGAR / cs / node path of one problem from the raw op stream (reverse order on the device)
     auto post_one = [&](uint64_t i) {
         const uint32_t p = order[i];
         poa_item &it = out[p];
-        it.ok = W.h_status.p[i] == POA_ST_OK ? 1 : 0;
-        it.score = W.h_score.p[i];
-        it.n_cells = W.h_cells.p[i];
-        it.n_vcells = W.h_vcells.p[i];
+        const poa_out &ho = W.h_outs.p[i];
+        it.ok = ho.status == POA_ST_OK ? 1 : 0;
+        it.score = ho.score;
+        it.n_cells = ho.cells;
+        it.n_vcells = ho.vcells;
         if (!it.ok) return;
         const poa_prep &g = G[p];
         const poa_prob &pb = probs[p];
@@ -1656,7 +1672,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         const uint32_t *pr = W.h_orow.p + pb.ops0;
         const char *q = views[p].query;
         const char *bases = views[p].nodes + views[p].node_off[0];  // row r is bases[r - 1]
-        const uint32_t nops = W.h_nops.p[i];
+        const uint32_t nops = ho.nops;
         std::string &cg = it.cigar, &cs = it.cs;
         cs = "cs:Z:";
         cg.reserve(nops / 2 + 16);
@@ -1709,58 +1725,82 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             it.end_off = it.rows.back() - g.first_row[it.gnodes.back()] + 1;
         }
     };
-    // Software pipeline: while the GPU runs sub-batch i+1 the host threads turn sub-batch i's op streams into
-    // CIGAR / cs strings.
+    // Software pipeline.  `todo` holds the launch-order ranges still to be enqueued (a sub-batch that overflowed its pool
+    // half goes back to the front); up to two sub-batches are in flight, one per stream; the host threads turn a finished
+    // sub-batch's op streams into CIGAR / cs strings while the GPU works on the next two.
     int rc_final = VGA_OK;
-    sub_t cur = launch(0, false);
-    while (true) {
-        POA_CHECK(hipStreamSynchronize(st));
+    std::vector<std::pair<uint64_t, uint64_t>> todo;  // used as a stack of [begin, end) ranges, front = back()
+    todo.push_back({0, n});
+    std::vector<sub_t> inflight;
+    bool slot_busy[2] = {false, false};
+    auto fill = [&]() {
+        while (inflight.size() < 2 && !todo.empty()) {
+            const int slot = slot_busy[0] ? 1 : 0;
+            auto &seg = todo.back();
+            sub_t sb = launch(seg.first, seg.second, slot);
+            if (sb.i1 >= seg.second) todo.pop_back();
+            else seg.first = sb.i1;
+            slot_busy[slot] = true;
+            inflight.push_back(sb);
+        }
+    };
+    fill();
+    while (!inflight.empty()) {
+        const sub_t cur = inflight.front();
+        inflight.erase(inflight.begin());
+        POA_CHECK(hipStreamSynchronize(sarr[cur.slot]));
+        slot_busy[cur.slot] = false;
         if (launch_err != hipSuccess)
             return vga_set_error(ctx, VGA_ERR_HIP, "POA launch failed: %s", hipGetErrorString(launch_err));
         bool pool_fail = false;
         for (uint64_t i = cur.i0; i < cur.i1; i++)
-            if (W.h_status.p[i] == POA_ST_POOL) pool_fail = true;
+            if (W.h_outs.p[i].status == POA_ST_POOL) pool_fail = true;
         if (pool_fail) {
-            if (cur.i1 - cur.i0 == 1 && W.pool_scale >= 4.0) { rc_final = VGA_ERR_POOL; break; }
-            W.pool_scale = std::min(8.0, W.pool_scale * 1.7);
-            cur = launch(cur.i0, false);  // rerun this sub-batch with a more cautious estimate
+            if (cur.i1 - cur.i0 == 1 && W.pool_scale >= 8.0) { rc_final = VGA_ERR_POOL; break; }
+            W.pool_scale = std::min(16.0, W.pool_scale * 1.7);
+            todo.push_back({cur.i0, cur.i1});  // enqueue it again, in smaller pieces
+            fill();
             continue;
         }
         if (cur.raw_est > 0) {
-            const double ratio = (double)W.h_next.p[0] / cur.raw_est;
+            const double ratio = (double)W.h_next.p[cur.slot] / cur.raw_est;
             W.pool_scale = std::max(ratio * 1.15, 0.6 * W.pool_scale + 0.4 * ratio * 1.25);
         }
         if (tr.on) {
             double worst = 0;
             uint32_t mx = 0;
             for (uint64_t i = cur.i0; i < cur.i1; i++) {
-                worst = std::max(worst, (double)W.h_maxw.p[i] / estw[order[i]]);
-                mx = std::max(mx, W.h_maxw.p[i]);
+                worst = std::max(worst, (double)W.h_outs.p[i].maxw / estw[order[i]]);
+                mx = std::max(mx, W.h_outs.p[i].maxw);
             }
-            fprintf(stderr, "[vga-trace] poa: sub-batch done, widest row %u columns, worst width / estimate %.3f\n", mx, worst);
+            fprintf(stderr, "[vga-trace] poa: sub-batch [%llu, %llu) done, pool %.1f GB, widest row %u columns, worst width / estimate %.3f\n",
+                    (unsigned long long)cur.i0, (unsigned long long)cur.i1, (double)W.h_next.p[cur.slot] / 1e9, mx, worst);
             const char *dump = getenv("VGA_POA_DUMP_WIDTHS");
             if (dump) {
                 FILE *f = fopen(dump, "a");
                 if (f) {
                     for (uint64_t i = cur.i0; i < cur.i1; i++)
                         fprintf(f, "%u %u %d %.0f %u %llu\n", G[order[i]].N, G[order[i]].qlen, G[order[i]].longest, estw[order[i]],
-                                W.h_maxw.p[i], (unsigned long long)W.h_cells.p[i]);
+                                W.h_outs.p[i].maxw, (unsigned long long)W.h_outs.p[i].cells);
                     fclose(f);
                 }
             }
         }
-        const bool have_next = cur.i1 < n;
-        sub_t nxt = cur;
-        if (have_next) { nxt = launch(cur.i1, false); }
+        fill();  // keep the GPU busy before the host-side post-processing of this sub-batch
         {
             const uint64_t a0 = cur.i0, cnt = cur.i1 - cur.i0;
             parallel_for(cnt, [&](uint64_t t) { post_one(a0 + t); });
         }
-        if (!have_next) break;
-        cur = nxt;
     }
+    // join the second stream into the context's stream (the caller only synchronises that one)
+    POA_CHECK(hipEventRecord(W.ev_join, W.st2));
+    POA_CHECK(hipStreamWaitEvent(st, W.ev_join, 0));
     vga_timer_end(ctx, t_total);
     tr.mark("dp + traceback + cigar (pipelined sub-batches)");
+    if (rc_final != VGA_OK) {
+        (void)hipStreamSynchronize(W.st2);
+        (void)hipStreamSynchronize(st);
+    }
     if (rc_final != VGA_OK)
         return vga_set_error(ctx, rc_final, "a single POA problem does not fit the %llu byte traceback pool",
                              (unsigned long long)W.pool_size);
@@ -1770,7 +1810,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     // + the value rows of node-end bases (4 B per cell packed, 6 B otherwise), written once and read back at least once
     uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
     for (uint64_t i = 0; i < n; i++) {
-        all_cells += W.h_cells.p[i]; all_vcells += W.h_vcells.p[i]; all_ops += W.h_nops.p[i];
+        all_cells += W.h_outs.p[i].cells; all_vcells += W.h_outs.p[i].vcells; all_ops += W.h_outs.p[i].nops;
         all_rows += G[i].N; all_q += G[i].qlen;
     }
     for (auto &a : ctx->last_times) {
@@ -1781,7 +1821,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         // mean band width per problem (cells / rows), 256-column buckets
         uint32_t hist[17] = {0};
         for (uint64_t i = 0; i < n; i++) {
-            const uint64_t wmean = W.h_cells.p[i] / (G[order[i]].N ? G[order[i]].N : 1);
+            const uint64_t wmean = W.h_outs.p[i].cells / (G[order[i]].N ? G[order[i]].N : 1);
             hist[std::min<uint64_t>(wmean / 256, 16)]++;
         }
         fprintf(stderr, "[vga-trace] poa: mean band width histogram (256-column buckets):");
