@@ -204,13 +204,18 @@ int vga_align_batch(vga_batch *b, const vga_map_result *chains, uint32_t align_b
 void vga_align_result_free(vga_align_result *r);
 
 /* Per-kernel timing of the most recent vga_map_batch / vga_poa_batch / vga_align_batch on this ctx:
- * name[i] / total milliseconds / launches, measured with hipEvents on the ctx's own stream.
+ * name[i] / total milliseconds / launches, measured with hipEvents on the stream each launch ran on.
+ * The POA sub-batches run two at a time on two streams: `ms` sums every launch's own duration (what
+ * rocprofv3 --kernel-trace --stats reports), `busy_ms` is the wall time during which at least one launch
+ * of that kernel was executing (the union of the launch intervals; equal to `ms` when nothing overlaps).
  * Returns the number of kernels (at most cap entries are written). */
 typedef struct {
     const char *name;
     float ms;
     uint32_t launches;
     uint64_t algorithmic_bytes; /* byte model of DESIGN.md for the units those launches processed */
+    float busy_ms;
+    uint32_t reserved;
 } vga_kernel_time;
 int vga_last_kernel_times(const vga_ctx *ctx, vga_kernel_time *out, int cap);
 

@@ -99,7 +99,8 @@ class AlignResult(C.Structure):
 
 
 class KernelTime(C.Structure):
-    _fields_ = [("name", C.c_char_p), ("ms", C.c_float), ("launches", C.c_uint32), ("algorithmic_bytes", C.c_uint64)]
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_float), ("launches", C.c_uint32), ("algorithmic_bytes", C.c_uint64),
+                ("busy_ms", C.c_float), ("reserved", C.c_uint32)]
 
 
 _lib = None
@@ -417,7 +418,7 @@ class Context:
         arr = (KernelTime * 32)()
         n = self.L.vga_last_kernel_times(self.h, arr, 32)
         return [{"name": arr[i].name.decode(), "ms": float(arr[i].ms), "launches": int(arr[i].launches),
-                 "algorithmic_bytes": int(arr[i].algorithmic_bytes)} for i in range(min(n, 32))]
+                 "algorithmic_bytes": int(arr[i].algorithmic_bytes), "busy_ms": float(arr[i].busy_ms)} for i in range(min(n, 32))]
 
     def synchronize(self):
         self._check(self.L.vga_ctx_synchronize(self.h))

@@ -15,7 +15,7 @@
 
 #include "../../include/vga_hip.h"
 
-#define VGA_ABI_VERSION 1
+#define VGA_ABI_VERSION 2
 
 struct vga_dev_index {
     uint32_t k = 0;
@@ -59,6 +59,7 @@ struct vga_ctx {
         float ms;
         uint32_t launches;
         uint64_t bytes;
+        float busy_ms;
     };
     std::vector<agg_t> last_times;
     int n_cu = 256;

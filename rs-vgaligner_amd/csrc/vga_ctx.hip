@@ -7,6 +7,8 @@
 // exact map gives the same answers, and 4^11 * 4 B = 16 MiB sits in the 256 MiB Infinity Cache.
 #include "vga_common.hpp"
 
+#include <algorithm>
+
 #include <malloc.h>
 
 int vga_set_error(vga_ctx *ctx, int code, const char *fmt, ...)
@@ -130,19 +132,38 @@ void vga_timer_end(vga_ctx *ctx, int idx)
 void vga_timers_collect(vga_ctx *ctx)
 {
     ctx->last_times.clear();
+    if (ctx->timers.empty()) return;
+    // launch intervals relative to the first recorded event (event pairs may sit on different streams)
+    const hipEvent_t ref = ctx->timers[0].e0;
+    std::vector<std::vector<std::pair<float, float>>> spans;
     for (const vga_timer_entry &t : ctx->timers) {
-        float ms = 0.f;
+        float ms = 0.f, a = 0.f;
         if (t.e0 && t.e1) (void)hipEventElapsedTime(&ms, t.e0, t.e1);
-        bool found = false;
-        for (auto &a : ctx->last_times)
-            if (a.name == t.name) {
-                a.ms += ms;
-                a.launches += 1;
-                a.bytes += t.bytes;
-                found = true;
-                break;
-            }
-        if (!found) ctx->last_times.push_back({t.name, ms, 1u, t.bytes});
+        if (ref && t.e0) (void)hipEventElapsedTime(&a, ref, t.e0);
+        size_t k = 0;
+        for (; k < ctx->last_times.size(); k++)
+            if (ctx->last_times[k].name == t.name) break;
+        if (k == ctx->last_times.size()) {
+            ctx->last_times.push_back({t.name, 0.f, 0u, 0ull, 0.f});
+            spans.emplace_back();
+        }
+        ctx->last_times[k].ms += ms;
+        ctx->last_times[k].launches += 1;
+        ctx->last_times[k].bytes += t.bytes;
+        spans[k].push_back({a, a + ms});
+    }
+    for (size_t k = 0; k < spans.size(); k++) {
+        std::sort(spans[k].begin(), spans[k].end());
+        float busy = 0.f, lo = 0.f, hi = -1.f;
+        for (const auto &iv : spans[k]) {
+            if (hi < lo || iv.first > hi) {
+                if (hi >= lo) busy += hi - lo;
+                lo = iv.first;
+                hi = iv.second;
+            } else if (iv.second > hi) hi = iv.second;
+        }
+        if (hi >= lo) busy += hi - lo;
+        ctx->last_times[k].busy_ms = busy;
     }
 }
 
@@ -164,6 +185,8 @@ extern "C" int vga_last_kernel_times(const vga_ctx *ctx, vga_kernel_time *out, i
         out[i].ms = ctx->last_times[i].ms;
         out[i].launches = ctx->last_times[i].launches;
         out[i].algorithmic_bytes = ctx->last_times[i].bytes;
+        out[i].busy_ms = ctx->last_times[i].busy_ms;
+        out[i].reserved = 0;
     }
     return n;
 }

@@ -92,6 +92,12 @@ struct poa_dev_params {
 //        lane parks in `edge` before the barrier.
 //      * Rows with a predecessor that is not the row directly above (bubble arms, multi-predecessor rows) read
 //        that predecessor's value row from HBM; such a row starts with a full __syncthreads() (vmcnt(0)).
+// -DPOA_MARKERS puts region markers into the ISA (tests/isa_regions.py counts instructions between them)
+#ifdef POA_MARKERS
+#define POA_MARK(name) asm volatile("; MARK " name)
+#else
+#define POA_MARK(name)
+#endif
 #define POA_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 template <int CTRL, int ROW_MASK>
@@ -676,8 +682,8 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     uint16_t *Qn = (uint16_t *)(smem + 4ull * hg_cols);          // [lds_cols / 4] four column codes per halfword
     int4 *sX = (int4 *)(smem + 4ull * hg_cols + ((lds_cols / 2 + 15u) & ~15u));  // [2][NW] {scan1, scan2, last1, last2} per wave
     int4 *sRed = sX + 2 * NW;         // [NW] {row max, -leftmost, rightmost, 0} per wave
-    int32_t *edgeW = (int32_t *)(sRed + NW);  // [2]
-    unsigned long long *s_alloc = (unsigned long long *)(edgeW + 2);
+    int32_t *edgeW = (int32_t *)(sRed + NW);  // [2] (+2 pad)
+    int4 *sRow = (int4 *)(edgeW + 4);         // [3] the row's parameters, written by wave 0 (see the row loop)
     const int edge_idx = (int)(edgeW - HG);  // edgeW addressed through HG, see phase 1
 
     const poa_prob pb = probs[blockIdx.x];
@@ -703,15 +709,16 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
         }
     };
 
+    // Wave 0 owns everything that is uniform per row and only needed to set the row up: the band pull, the pool
+    // allocator, the row record, the counters.  It publishes the row's parameters in sRow; the other waves pick them up
+    // after one LDS barrier instead of recomputing ~350 scalar instructions each.
+    const bool leader = wv == 0;
     uint64_t dcur = 0, dend = 0, vcur = 0, vendp = 0;
     bool failed = false;
-    bool prev_lds = true;  // the row just computed is resident in the LDS window (false after a row wider than the window)
     int maxw = 0;
-    auto take_chunk = [&](uint64_t &cur, uint64_t &end) {
-        __syncthreads();
-        if (tid == 0) *s_alloc = atomicAdd(pool_next, (unsigned long long)POA_CHUNK);
-        __syncthreads();
-        const uint64_t bv = *s_alloc;  // uniform: keep the allocator state in scalar registers
+    auto take_chunk = [&](uint64_t &cur, uint64_t &end) {  // wave 0 only
+        unsigned long long bv = 0;
+        if (lane == 0) bv = atomicAdd(pool_next, (unsigned long long)POA_CHUNK);
         const uint64_t b = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bv >> 32)) << 32) |
                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv);
         if (b + POA_CHUNK > pool_size) failed = true;
@@ -748,21 +755,24 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
 
     // two scratch value rows for rows wider than the LDS window (they only feed the row directly below)
     uint64_t wide_scratch = 0;
-    if (win_mask != 0xFFFFFFFFu) wide_scratch = alloc(vcur, vendp, 8ull * lds_cols);
+    if (leader && win_mask != 0xFFFFFFFFu) wide_scratch = alloc(vcur, vendp, 8ull * lds_cols);
     int prev_beg = 0, prev_end = -1, prev_lmax = 0, prev_rmax = 0;
+    bool prev_lds = true;  // the row just computed is resident in the LDS window (false after a row wider than the window)
     uint64_t cells = 0, vcells = 0;
     uint32_t seq_word = 0, seq_word_idx = 0xFFFFFFFFu;
+    bool stop = false;
 
-    for (uint32_t v = 0; v < pb.n_nodes && !failed; v++) {  // (a failed scratch allocation ends here as well)
+    for (uint32_t v = 0; v < pb.n_nodes && !stop; v++) {
     const uint4 nt = ntab[v];
     const uint32_t nlen = nt.y & 0xFFFFFFu;
-    for (uint32_t tn = 0; tn < nlen && !failed; tn++) {
+    for (uint32_t tn = 0; tn < nlen && !stop; tn++) {
+        POA_MARK("row_topo");
+        // ---- every wave: the row's place in the graph
         const uint32_t r = nt.x + tn;
         const bool first = tn == 0 && v > 0;
         const bool last = tn + 1 == nlen;
         const int np = v == 0 ? 0 : (tn == 0 ? (int)(nt.y >> 24) : 1);
         const uint32_t ps = nt.w;
-        const int remain = (int)nt.z + (int)(nlen - 1 - tn);
         uint8_t gb = 0;
         if (v > 0) {
             const uint32_t bi = r - 1;
@@ -777,75 +787,98 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
             else
                 for (int t = 0; t < np; t++) far |= plist[ps + t] != r - 1;
         }
-        if (far) __syncthreads();  // vmcnt(0) + barrier: the value rows / row arrays of far predecessors have landed
-        int mpl, mpr;
-        if (r == 0) { mpl = 0; mpr = 0; }
-        else if (!first) { mpl = prev_lmax + 1; mpr = prev_rmax + 1; }
-        else {
-            mpl = INT32_MAX; mpr = 0;
-            for (int t = 0; t < np; t++) {
-                const uint32_t p = np == 1 ? ps : plist[ps + t];
-                int lm, rm;
-                if (p == r - 1) { lm = prev_lmax + 1; rm = prev_rmax + 1; }
-                else { lm = R[p].lmax + 1; rm = R[p].rmax + 1; }
-                mpl = lm < mpl ? lm : mpl;
-                mpr = rm > mpr ? rm : mpr;
+        if (far) __syncthreads();  // vmcnt(0) + barrier: the value rows / row records of far predecessors have landed
+        const bool single = r > 0 && np == 1;   // one predecessor (the row above in LDS, or a far row in HBM)
+        const uint32_t sp = first ? ps : r - 1;  // that predecessor
+        const bool sp_near = sp == r - 1 && prev_lds;
+        POA_MARK("row_leader");
+        // ---- wave 0: band, pool space, row record
+        if (leader) {
+            const int remain = (int)nt.z + (int)(nlen - 1 - tn);
+            int mpl, mpr;
+            if (r == 0) { mpl = 0; mpr = 0; }
+            else if (!first) { mpl = prev_lmax + 1; mpr = prev_rmax + 1; }
+            else {
+                mpl = INT32_MAX; mpr = 0;
+                for (int t = 0; t < np; t++) {
+                    const uint32_t p = np == 1 ? ps : plist[ps + t];
+                    int lm, rm;
+                    if (p == r - 1) { lm = prev_lmax + 1; rm = prev_rmax + 1; }
+                    else {
+                        lm = __builtin_amdgcn_readfirstlane(R[p].lmax) + 1;
+                        rm = __builtin_amdgcn_readfirstlane(R[p].rmax) + 1;
+                    }
+                    mpl = lm < mpl ? lm : mpl;
+                    mpr = rm > mpr ? rm : mpr;
+                }
+            }
+            int beg, end;
+            if (!P.banded) { beg = 0; end = qlen; }
+            else {
+                const int diag = qlen - remain;
+                const int lo = mpl < diag ? mpl : diag;
+                const int hi = mpr > diag ? mpr : diag;
+                beg = lo - bw; if (beg < 0) beg = 0;
+                end = hi + bw; if (end > qlen) end = qlen;
+            }
+            const int W = (end - (beg & ~3) + 1 + 3) & ~3;
+            maxw = W > maxw ? W : maxw;
+            const bool wide = (uint32_t)W + 8u > hg_cols;
+            if (r > 0) cells += (uint64_t)(end - beg + 1);
+            if (last || wide) vcells += (uint64_t)(end - beg + 1);
+            const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u));
+            uint64_t voff = 0;
+            if (last && !failed) voff = alloc(vcur, vendp, 4ull * (uint64_t)W);
+            else if (wide) voff = wide_scratch + (r & 1u) * 4ull * lds_cols;
+            int pbeg = prev_beg, pend = prev_end;
+            uint64_t vpo = 0;
+            if (single && !sp_near) {
+                // uniform values of a far row: read them into scalar registers right here, so that their s_waitcnt vmcnt
+                // stays inside this branch
+                pbeg = __builtin_amdgcn_readfirstlane(R[sp].beg);
+                pend = __builtin_amdgcn_readfirstlane(R[sp].end);
+                const uint64_t vo = R[sp].voff;
+                vpo = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(vo >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vo);
+            }
+            if (lane == 0) {
+                if (!failed) {
+                    R[r].beg = beg; R[r].end = end;
+                    R[r].doff = doff; R[r].voff = voff;
+                    R[r].pred = ps; R[r].npred = first ? (uint32_t)np : 0u;
+                }
+                sRow[0] = make_int4(beg, end, (int)(uint32_t)doff, (int)(uint32_t)(doff >> 32));
+                sRow[1] = make_int4((int)(uint32_t)voff, (int)(uint32_t)(voff >> 32), pbeg, pend);
+                sRow[2] = make_int4((int)(uint32_t)vpo, (int)(uint32_t)(vpo >> 32), failed ? 1 : 0, 0);
             }
         }
-        int beg, end;
-        if (!P.banded) { beg = 0; end = qlen; }
-        else {
-            const int diag = qlen - remain;
-            const int lo = mpl < diag ? mpl : diag;
-            const int hi = mpr > diag ? mpr : diag;
-            beg = lo - bw; if (beg < 0) beg = 0;
-            end = hi + bw; if (end > qlen) end = qlen;
-        }
+        POA_LDS_BARRIER();
+        POA_MARK("row_pickup");
+        // ---- every wave: pick the parameters up
+        const int4 rw0 = sRow[0], rw1 = sRow[1], rw2 = sRow[2];
+        const int beg = __builtin_amdgcn_readfirstlane(rw0.x), end = __builtin_amdgcn_readfirstlane(rw0.y);
+        const uint64_t doff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(rw0.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(rw0.z);
+        const uint64_t voff = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(rw1.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(rw1.x);
+        const int pbeg = __builtin_amdgcn_readfirstlane(rw1.z), pend = __builtin_amdgcn_readfirstlane(rw1.w);
+        const uint64_t vpo = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(rw2.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(rw2.x);
+        if (__builtin_amdgcn_readfirstlane(rw2.z)) { stop = true; break; }
         const int bal = beg & ~3;
         const int W = (end - bal + 1 + 3) & ~3;  // storage width / plane stride
-        maxw = W > maxw ? W : maxw;
         // A row wider than the LDS window (columns would alias) is not written to LDS: it keeps a value row in HBM like
-        // a node-end row does, and the row below reads it from there.
+        // a node-end row does (in one of two scratch rows unless it ends a node), and the row below reads it from there.
         const bool wide = (uint32_t)W + 8u > hg_cols;
         const bool keep = last || wide;
-        if (r > 0) cells += (uint64_t)(end - beg + 1);
-        if (keep) vcells += (uint64_t)(end - beg + 1);
-        const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u));
-        if (failed) break;
-        uint64_t voff = 0;
-        if (last) { voff = alloc(vcur, vendp, 4ull * (uint64_t)W); if (failed) break; }
-        else if (wide) voff = wide_scratch + (r & 1u) * 4ull * lds_cols;
-        if (tid == 0) {
-            R[r].beg = beg; R[r].end = end;
-            R[r].doff = doff; R[r].voff = voff;
-            R[r].pred = ps; R[r].npred = first ? (uint32_t)np : 0u;
-        }
         int32_t *Vrow = (int32_t *)(pool + voff);  // value row: packed words
         uint8_t *drow = pool + doff;
         const int gcode = gb == 'A' ? 0 : (gb == 'C' ? 1 : (gb == 'G' ? 2 : (gb == 'T' ? 3 : 4)));
         const int sc_eq = gcode == 4 ? 0 : P.match, sc_ne = gcode == 4 ? 0 : -P.mismatch;
         const int gsh = gcode & 3;            // bit of the one-hot column code that means "equal to this row's base"
         const int sc_mm = sc_eq - sc_ne;
-        // one predecessor (the row above in LDS, or a far row in HBM): the branch-free lean path applies
-        const bool single = r > 0 && np == 1;
-        const uint32_t sp = first ? ps : r - 1;  // that predecessor
-        const bool sp_near = sp == r - 1 && prev_lds;
-        int pbeg = prev_beg, pend = prev_end;
-        const int32_t *Vp = nullptr;
-        int balp = 0;
-        if (single && !sp_near) {
-            // uniform values of a far row: read them into scalar registers right here, so that their s_waitcnt vmcnt
-            // stays inside this branch (in shared code it would make every row wait for its predecessors' stores)
-            pbeg = __builtin_amdgcn_readfirstlane(R[sp].beg);
-            pend = __builtin_amdgcn_readfirstlane(R[sp].end);
-            const uint64_t vo = R[sp].voff;
-            const uint64_t vos = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(vo >> 32)) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vo);
-            Vp = (const int32_t *)(pool + vos);
-            balp = pbeg & ~3;
-        }
+        const int32_t *Vp = (const int32_t *)(pool + vpo);
+        const int balp = pbeg & ~3;
         stamp(0);
 
+        POA_MARK("row_steps");
         int carry1 = POA_IDENT, carry2 = POA_IDENT, left1 = POA_IDENT, left2 = POA_IDENT;
         int best = INT32_MIN, lpos = beg, rpos = beg;
         int buf = 0;
@@ -868,6 +901,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
             const int jw0 = bal + c0 + 64 * CPT * wv;
             const bool fastw = single && q_plain && jw0 > pbeg && jw0 >= beg && jw0 + 64 * CPT - 1 <= end && jw0 + 64 * CPT - 1 <= pend;
             const int base1 = e1 * j0, base2 = e2 * j0;  // the max-plus scan runs on lane-relative values in the fast path
+        POA_MARK("p1_fast");
             if (fastw) {
                 // ---------------- interior path, phase 1
                 int4 hv;
@@ -914,6 +948,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                 }
                 agg1 = ag1 + base1;
                 agg2 = ag2 + base2;
+        POA_MARK("p1_lean");
             } else if (wave_act && single) {
                 // ---------------- lean path, phase 1
                 int wj[CPT], wm0;
@@ -962,6 +997,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                     if (k == CPT - 1) { alast1 = a1; alast2 = a2; }
                     inprev = inj;
                 }
+        POA_MARK("p1_general");
             } else if (wave_act) {
                 // ---------------- general path, phase 1: the source row and rows with several predecessors
                 if (r == 0) {
@@ -1042,6 +1078,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                     if (k == CPT - 1) { alast1 = a1; alast2 = a2; }
                 }
             }
+        POA_MARK("scan");
             stamp(1);
             int i1 = POA_IDENT, i2 = POA_IDENT;
             if (wave_act) {
@@ -1052,6 +1089,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
             stamp(2);
             POA_LDS_BARRIER();
             stamp(3);
+        POA_MARK("exchange");
             // lane q < NW picks up wave q's totals; an 8-lane DPP scan gives every wave its prefix and the step total
             int4 xw = make_int4(INT32_MIN, INT32_MIN, POA_IDENT, POA_IDENT);
             if (lane < NW) xw = sX[buf * NW + lane];
@@ -1083,6 +1121,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                 if (lane == 0) { la1 = pl1; la2 = pl2; }
                 int run1 = pre1 > x1 ? pre1 : x1;
                 int run2 = pre2 > x2 ? pre2 : x2;
+        POA_MARK("p2_fast");
                 if (fastw) {
                     // ---------------- interior path, phase 2
                     int wv4[CPT], codev[CPT];
@@ -1110,6 +1149,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                     if (!wide) *(int4 *)(HG + (j0 & win_mask)) = wq;
                     *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
                     if (keep) *(int4 *)(Vrow + c) = wq;
+        POA_MARK("p2_slow");
                 } else if (lane_act) {
                     int wv4[CPT], codev[CPT];
 #pragma unroll
@@ -1146,9 +1186,11 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                     }
                 }
             }
+        POA_MARK("step_end");
             carry1 = all1; carry2 = all2;
             left1 = nleft1; left2 = nleft2;
         }
+        POA_MARK("row_reduce");
         stamp(4);
         {
             int wb = poa_wave_scan_max(best);
@@ -1182,6 +1224,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
             lpos = -__builtin_amdgcn_readlane(lm, NW - 1);
             rpos = __builtin_amdgcn_readlane(rm, NW - 1);
         }
+        POA_MARK("row_end");
         if (tid == 0) { R[r].lmax = lpos; R[r].rmax = rpos; }
         prev_beg = beg; prev_end = end; prev_lmax = lpos; prev_rmax = rpos;
         prev_lds = !wide;
@@ -1224,7 +1267,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
 static inline size_t poa_pk_lds_bytes(uint32_t hg_cols, uint32_t lds_cols, int nt)
 {
     const int nw = nt / 64;
-    return 4ull * hg_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw) * 16 + 2 * 4 + 8 + 16;
+    return 4ull * hg_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw) * 16 + 16 + 48 + 16;
 }
 
 static inline uint32_t poa_lds_cols(uint32_t max_q) { return ((max_q + 1 + 15u) & ~15u) + 16u; }
