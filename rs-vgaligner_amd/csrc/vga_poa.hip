@@ -27,6 +27,7 @@
 #include "vga_poa_internal.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <chrono>
 #include <thread>
 
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
     const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
     poa_dev_params P, poa_row *rows, uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size,
-    poa_out *__restrict__ outs, uint32_t lds_cols, uint32_t hg_cols, uint32_t win_mask, int g1bits,
+    poa_out *__restrict__ outs, uint32_t lds_cols, uint32_t hg_cols, uint32_t win_mask, int g1bits_dbg,
     unsigned long long *stamps = nullptr)
 {
     constexpr int CPT = 4;
@@ -684,6 +685,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     int4 *sRed = sX + 2 * NW;         // [NW] {row max, -leftmost, rightmost, 0} per wave
     int32_t *edgeW = (int32_t *)(sRed + NW);  // [2] (+2 pad)
     int4 *sRow = (int4 *)(edgeW + 4);         // [3] the row's parameters, written by wave 0 (see the row loop)
+    int4 *sLead = sRow + 3;                   // [4] wave 0's allocator state and counters
     const int edge_idx = (int)(edgeW - HG);  // edgeW addressed through HG, see phase 1
 
     const poa_prob pb = probs[blockIdx.x];
@@ -694,6 +696,8 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     const uint32_t *plist = preds + pb.pred0;
     poa_row *R = rows + pb.row0;
 
+    const int g1bits = g1bits_dbg & 255;
+    const bool dbg_no_fast = (g1bits_dbg >> 8) & 1, dbg_no_edge = (g1bits_dbg >> 9) & 1;  // VGA_POA_DEBUG (diagnostics)
     const int o1 = P.o1, e1 = P.e1, o2 = P.o2, e2 = P.e2;
     const int oe1 = o1 + e1, oe2 = o2 + e2;
     const int g1mask = (1 << g1bits) - 1;
@@ -711,23 +715,40 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
 
     // Wave 0 owns everything that is uniform per row and only needed to set the row up: the band pull, the pool
     // allocator, the row record, the counters.  It publishes the row's parameters in sRow; the other waves pick them up
-    // after one LDS barrier instead of recomputing ~350 scalar instructions each.
+    // after one LDS barrier instead of recomputing ~350 scalar instructions each.  Its own state (allocator cursors,
+    // counters) lives in LDS (sLead) and is handled in vector registers inside the leader block, so that it does not
+    // occupy scalar registers across the row loop (the kernel is short of them: every spilled SGPR costs v_writelane /
+    // v_readlane instructions in all waves).
     const bool leader = wv == 0;
-    uint64_t dcur = 0, dend = 0, vcur = 0, vendp = 0;
-    bool failed = false;
-    int maxw = 0;
-    auto take_chunk = [&](uint64_t &cur, uint64_t &end) {  // wave 0 only
+    struct lead_t {
+        uint64_t dcur, dend, vcur, vendp, wide_scratch, cells, vcells;
+        int maxw, failed;
+    };
+    auto lead_load = [&]() -> lead_t {
+        const int4 a = sLead[0], b = sLead[1], c = sLead[2], d = sLead[3];
+        auto u64 = [](int lo, int hi) { return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; };
+        return {u64(a.x, a.y), u64(a.z, a.w), u64(b.x, b.y), u64(b.z, b.w), u64(c.x, c.y), u64(c.z, c.w), u64(d.x, d.y), d.z, d.w};
+    };
+    auto lead_store = [&](const lead_t &L) {
+        if (lane == 0) {
+            sLead[0] = make_int4((int)(uint32_t)L.dcur, (int)(uint32_t)(L.dcur >> 32), (int)(uint32_t)L.dend, (int)(uint32_t)(L.dend >> 32));
+            sLead[1] = make_int4((int)(uint32_t)L.vcur, (int)(uint32_t)(L.vcur >> 32), (int)(uint32_t)L.vendp, (int)(uint32_t)(L.vendp >> 32));
+            sLead[2] = make_int4((int)(uint32_t)L.wide_scratch, (int)(uint32_t)(L.wide_scratch >> 32), (int)(uint32_t)L.cells, (int)(uint32_t)(L.cells >> 32));
+            sLead[3] = make_int4((int)(uint32_t)L.vcells, (int)(uint32_t)(L.vcells >> 32), L.maxw, L.failed);
+        }
+    };
+    auto take_chunk = [&](lead_t &L, uint64_t &cur, uint64_t &end) {  // wave 0 only
         unsigned long long bv = 0;
         if (lane == 0) bv = atomicAdd(pool_next, (unsigned long long)POA_CHUNK);
         const uint64_t b = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bv >> 32)) << 32) |
                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv);
-        if (b + POA_CHUNK > pool_size) failed = true;
+        if (b + POA_CHUNK > pool_size) L.failed = 1;
         cur = b;
         end = b + POA_CHUNK;
     };
-    auto alloc = [&](uint64_t &cur, uint64_t &end, uint64_t bytes) -> uint64_t {
+    auto alloc = [&](lead_t &L, uint64_t &cur, uint64_t &end, uint64_t bytes) -> uint64_t {
         bytes = (bytes + 15ull) & ~15ull;
-        if (cur + bytes > end) take_chunk(cur, end);
+        if (cur + bytes > end) take_chunk(L, cur, end);
         uint64_t r = cur;
         cur += bytes;
         return r;
@@ -753,12 +774,14 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     // the branch-free interior path assumes every query base scores match or mismatch
     const bool q_plain = __syncthreads_or(non_acgt) == 0;
 
-    // two scratch value rows for rows wider than the LDS window (they only feed the row directly below)
-    uint64_t wide_scratch = 0;
-    if (leader && win_mask != 0xFFFFFFFFu) wide_scratch = alloc(vcur, vendp, 8ull * lds_cols);
+    if (leader) {
+        lead_t L = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // two scratch value rows for rows wider than the LDS window (they only feed the row directly below)
+        if (win_mask != 0xFFFFFFFFu) L.wide_scratch = alloc(L, L.vcur, L.vendp, 8ull * lds_cols);
+        lead_store(L);
+    }
     int prev_beg = 0, prev_end = -1, prev_lmax = 0, prev_rmax = 0;
     bool prev_lds = true;  // the row just computed is resident in the LDS window (false after a row wider than the window)
-    uint64_t cells = 0, vcells = 0;
     uint32_t seq_word = 0, seq_word_idx = 0xFFFFFFFFu;
     bool stop = false;
 
@@ -794,6 +817,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
         POA_MARK("row_leader");
         // ---- wave 0: band, pool space, row record
         if (leader) {
+            lead_t L = lead_load();
             const int remain = (int)nt.z + (int)(nlen - 1 - tn);
             int mpl, mpr;
             if (r == 0) { mpl = 0; mpr = 0; }
@@ -822,14 +846,14 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                 end = hi + bw; if (end > qlen) end = qlen;
             }
             const int W = (end - (beg & ~3) + 1 + 3) & ~3;
-            maxw = W > maxw ? W : maxw;
+            L.maxw = W > L.maxw ? W : L.maxw;
             const bool wide = (uint32_t)W + 8u > hg_cols;
-            if (r > 0) cells += (uint64_t)(end - beg + 1);
-            if (last || wide) vcells += (uint64_t)(end - beg + 1);
-            const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u));
+            if (r > 0) L.cells += (uint64_t)(end - beg + 1);
+            if (last || wide) L.vcells += (uint64_t)(end - beg + 1);
+            const uint64_t doff = alloc(L, L.dcur, L.dend, (uint64_t)W * (np > 1 ? 4u : 1u));
             uint64_t voff = 0;
-            if (last && !failed) voff = alloc(vcur, vendp, 4ull * (uint64_t)W);
-            else if (wide) voff = wide_scratch + (r & 1u) * 4ull * lds_cols;
+            if (last && !L.failed) voff = alloc(L, L.vcur, L.vendp, 4ull * (uint64_t)W);
+            else if (wide) voff = L.wide_scratch + (r & 1u) * 4ull * lds_cols;
             int pbeg = prev_beg, pend = prev_end;
             uint64_t vpo = 0;
             if (single && !sp_near) {
@@ -841,15 +865,16 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                 vpo = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(vo >> 32)) << 32) |
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vo);
             }
+            lead_store(L);
             if (lane == 0) {
-                if (!failed) {
+                if (!L.failed) {
                     R[r].beg = beg; R[r].end = end;
                     R[r].doff = doff; R[r].voff = voff;
                     R[r].pred = ps; R[r].npred = first ? (uint32_t)np : 0u;
                 }
                 sRow[0] = make_int4(beg, end, (int)(uint32_t)doff, (int)(uint32_t)(doff >> 32));
                 sRow[1] = make_int4((int)(uint32_t)voff, (int)(uint32_t)(voff >> 32), pbeg, pend);
-                sRow[2] = make_int4((int)(uint32_t)vpo, (int)(uint32_t)(vpo >> 32), failed ? 1 : 0, 0);
+                sRow[2] = make_int4((int)(uint32_t)vpo, (int)(uint32_t)(vpo >> 32), L.failed, 0);
             }
         }
         POA_LDS_BARRIER();
@@ -896,11 +921,22 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
 #pragma unroll
             for (int k = 0; k < CPT; k++) { ht[k] = POA_NEG; meta[k] = (o1 << 8) | (o2 << 16); pmeta[k] = 0; wold[k] = 0; }
             const uint32_t qn = wave_act ? (uint32_t)Qn[j0 >> 2] : 0u;
-            // Interior wave of a single-predecessor row: all of its 256 columns, and the column to their left, lie
-            // inside this row's band and the predecessor's, and every query base is A/C/G/T -> no per-cell masks.
-            const int jw0 = bal + c0 + 64 * CPT * wv;
-            const bool fastw = single && q_plain && jw0 > pbeg && jw0 >= beg && jw0 + 64 * CPT - 1 <= end && jw0 + 64 * CPT - 1 <= pend;
+            // Fast path of a single-predecessor row (every query base A/C/G/T): no per-cell band masks.  It needs every
+            // ACTIVE cell of the wave, and the column to its left, inside the predecessor's band.  Two cheap patches let
+            // the band's edge waves take it too:
+            //  lp  the wave starts left of `beg` (only lane 0's first cells): those cells are computed from whatever
+            //      the LDS holds and their Ht is then replaced by POA_IDENT, so they stay out of the max-plus scan;
+            //  rp  the wave reaches past `end` or `pend`: words right of `pend` are replaced by (NEG, g = 0), which
+            //      gives E = NEG exactly; allowed when at most column pend+1 is active (its M comes from pend), and
+            //      only for LDS predecessors (the HBM row ends at pend).  Cells right of `end` are kept out of the
+            //      row maximum and are not stored.
+            const int jw0 = bal + c0 + 64 * CPT * wv, jw1 = jw0 + 64 * CPT - 1;
+            const bool lp = jw0 < beg;
+            const bool rp = jw1 > end || jw1 > pend;
+            const bool fastw = single && q_plain && wave_act && (lp ? beg : jw0) > pbeg && (!rp || (sp_near && end <= pend + 1)) &&
+                               !dbg_no_fast && !(dbg_no_edge && (lp || rp));
             const int base1 = e1 * j0, base2 = e2 * j0;  // the max-plus scan runs on lane-relative values in the fast path
+            if constexpr (STAMP) tacc[7] += (wave_act ? (1ull << 42) : 0ull) + (fastw ? 1ull : 0ull) + ((fastw && (lp || rp)) ? (1ull << 21) : 0ull);
         POA_MARK("p1_fast");
             if (fastw) {
                 // ---------------- interior path, phase 1
@@ -911,43 +947,64 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                     if (tid == NT - 1) edgeW[buf] = hv.w;
                     // one LDS read through an index (a pointer select would turn into a flat load, which also waits
                     // for the outstanding global stores)
-                    hprev = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : ((j0 - 1) & win_mask)];
+                    hprev = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : ((j0 > 0 ? j0 - 1 : 0) & win_mask)];
                     asm volatile("" : "+v"(hprev));
                     hprev >>= 8;
                 } else {
                     hv = *(const int4 *)(Vp + (j0 - balp));
-                    hprev = Vp[j0 - balp - 1];
+                    hprev = Vp[j0 - balp > 0 ? j0 - balp - 1 : 0];
                     // consume the loads inside this branch: otherwise their s_waitcnt vmcnt lands in the code shared
                     // with near rows, where it would also wait for every outstanding direction / value store
                     asm volatile("" : "+v"(hv.x), "+v"(hv.y), "+v"(hv.z), "+v"(hv.w), "+v"(hprev));
                     hprev >>= 8;
                 }
                 stamp(6);
-                const int wj[CPT] = {hv.x, hv.y, hv.z, hv.w};
-                const uint32_t eqb = qn >> gsh;
-                int ag1 = POA_IDENT, ag2 = POA_IDENT;
+                // the pure interior variant and the edge variant (with the lp / rp patches) are separate instantiations
+                auto phase1 = [&](auto edge_c) {
+                    constexpr bool EDGE = decltype(edge_c)::value;
+                    int wj[CPT] = {hv.x, hv.y, hv.z, hv.w};
+                    if constexpr (EDGE) {
+                        if (rp) {
 #pragma unroll
-                for (int k = 0; k < CPT; k++) {
-                    const int hj = wj[k] >> 8;
-                    const int g1 = wj[k] & g1mask, g2 = (int)__builtin_amdgcn_ubfe((uint32_t)wj[k], (uint32_t)g1bits, (uint32_t)g2w);
-                    const int m = (hprev + sc_ne) + (int)((eqb >> (4 * k)) & 1u) * sc_mm;
-                    const int ev1 = hj - g1, ev2 = hj - g2;
-                    const int me = m > ev1 ? m : ev1;
-                    const int h = me > ev2 ? me : ev2;
-                    const int hts = ev2 > me ? 2 : (ev1 > m ? 1 : 0);
-                    const int ofl = (g1 == oe1 ? 4 : 0) | (g2 == oe2 ? 8 : 0);
-                    int u1 = h - ev1; u1 = u1 < o1 ? u1 : o1;
-                    int u2 = h - ev2; u2 = u2 < o2 ? u2 : o2;
-                    ht[k] = h;
-                    meta[k] = hts | ofl | (u1 << 8) | (u2 << 16);
-                    const int r1 = h + e1 * k, r2 = h + e2 * k;
-                    ag1 = r1 > ag1 ? r1 : ag1;
-                    ag2 = r2 > ag2 ? r2 : ag2;
-                    if (k == CPT - 1) { alast1 = r1 + base1; alast2 = r2 + base2; }
-                    hprev = hj;
-                }
-                agg1 = ag1 + base1;
-                agg2 = ag2 + base2;
+                            for (int k = 0; k < CPT; k++) wj[k] = j0 + k > pend ? (int)((uint32_t)POA_NEG << 8) : wj[k];
+                        }
+                    }
+                    const uint32_t eqb = qn >> gsh;
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) {
+                        const int hj = wj[k] >> 8;
+                        const int g1 = wj[k] & g1mask, g2 = (int)__builtin_amdgcn_ubfe((uint32_t)wj[k], (uint32_t)g1bits, (uint32_t)g2w);
+                        const int m = (hprev + sc_ne) + (int)((eqb >> (4 * k)) & 1u) * sc_mm;
+                        const int ev1 = hj - g1, ev2 = hj - g2;
+                        const int me = m > ev1 ? m : ev1;
+                        const int h = me > ev2 ? me : ev2;
+                        const int hts = ev2 > me ? 2 : (ev1 > m ? 1 : 0);
+                        const int ofl = (g1 == oe1 ? 4 : 0) | (g2 == oe2 ? 8 : 0);
+                        int u1 = h - ev1; u1 = u1 < o1 ? u1 : o1;
+                        int u2 = h - ev2; u2 = u2 < o2 ? u2 : o2;
+                        ht[k] = h;
+                        meta[k] = hts | ofl | (u1 << 8) | (u2 << 16);
+                        hprev = hj;
+                    }
+                    if constexpr (EDGE) {
+                        if (lp) {
+#pragma unroll
+                            for (int k = 0; k < CPT; k++) ht[k] = j0 + k < beg ? POA_IDENT : ht[k];
+                        }
+                    }
+                    int ag1 = POA_IDENT, ag2 = POA_IDENT;
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) {
+                        const int r1 = ht[k] + e1 * k, r2 = ht[k] + e2 * k;
+                        ag1 = r1 > ag1 ? r1 : ag1;
+                        ag2 = r2 > ag2 ? r2 : ag2;
+                        if (k == CPT - 1) { alast1 = r1 + base1; alast2 = r2 + base2; }
+                    }
+                    agg1 = ag1 + base1;
+                    agg2 = ag2 + base2;
+                };
+                if (lp || rp) phase1(std::true_type{});
+                else phase1(std::false_type{});
         POA_MARK("p1_lean");
             } else if (wave_act && single) {
                 // ---------------- lean path, phase 1
@@ -1124,31 +1181,40 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
         POA_MARK("p2_fast");
                 if (fastw) {
                     // ---------------- interior path, phase 2
-                    int wv4[CPT], codev[CPT];
-                    int R1 = run1 - base1, R2 = run2 - base2, L1 = la1 - base1, L2 = la2 - base2;
+                    auto phase2 = [&](auto edge_c) {
+                        constexpr bool EDGE = decltype(edge_c)::value;
+                        int wv4[CPT], codev[CPT];
+                        int R1 = run1 - base1, R2 = run2 - base2, L1 = la1 - base1, L2 = la2 - base2;
 #pragma unroll
-                    for (int k = 0; k < CPT; k++) {
-                        const int j = j0 + k;
-                        const int f1 = R1 - (o1 + e1 * k), f2 = R2 - (o2 + e2 * k);
-                        const int fo = (R1 == L1 ? 64 : 0) | (R2 == L2 ? 128 : 0);
-                        const int hf = ht[k] > f1 ? ht[k] : f1;
-                        const int h = hf > f2 ? hf : f2;
-                        const int fsel = f2 > hf ? 32 : (f1 > ht[k] ? 16 : 0);
-                        codev[k] = (meta[k] & 15) | fsel | fo;
-                        const int dh = h - ht[k];
-                        int dd1 = ((meta[k] >> 8) & 255) + dh; dd1 = (dd1 < o1 ? dd1 : o1) + e1;
-                        int dd2 = ((meta[k] >> 16) & 255) + dh; dd2 = (dd2 < o2 ? dd2 : o2) + e2;
-                        wv4[k] = (int)(((uint32_t)h << 8) | (uint32_t)(dd1 | (dd2 << g1bits)));
-                        if (h > best) { best = h; lpos = j; rpos = j; }
-                        else if (h == best) rpos = j;
-                        L1 = ht[k] + e1 * k; L2 = ht[k] + e2 * k;
-                        R1 = L1 > R1 ? L1 : R1;
-                        R2 = L2 > R2 ? L2 : R2;
-                    }
-                    const int4 wq = make_int4(wv4[0], wv4[1], wv4[2], wv4[3]);
-                    if (!wide) *(int4 *)(HG + (j0 & win_mask)) = wq;
-                    *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
-                    if (keep) *(int4 *)(Vrow + c) = wq;
+                        for (int k = 0; k < CPT; k++) {
+                            const int j = j0 + k;
+                            const int f1 = R1 - (o1 + e1 * k), f2 = R2 - (o2 + e2 * k);
+                            const int fo = (R1 == L1 ? 64 : 0) | (R2 == L2 ? 128 : 0);
+                            const int hf = ht[k] > f1 ? ht[k] : f1;
+                            const int h = hf > f2 ? hf : f2;
+                            const int fsel = f2 > hf ? 32 : (f1 > ht[k] ? 16 : 0);
+                            codev[k] = (meta[k] & 15) | fsel | fo;
+                            const int dh = h - ht[k];
+                            int dd1 = ((meta[k] >> 8) & 255) + dh; dd1 = (dd1 < o1 ? dd1 : o1) + e1;
+                            int dd2 = ((meta[k] >> 16) & 255) + dh; dd2 = (dd2 < o2 ? dd2 : o2) + e2;
+                            wv4[k] = (int)(((uint32_t)h << 8) | (uint32_t)(dd1 | (dd2 << g1bits)));
+                            int hb = h;
+                            if constexpr (EDGE) hb = j > end ? INT32_MIN : h;
+                            if (hb > best) { best = hb; lpos = j; rpos = j; }
+                            else if (hb == best) rpos = j;
+                            L1 = ht[k] + e1 * k; L2 = ht[k] + e2 * k;
+                            R1 = L1 > R1 ? L1 : R1;
+                            R2 = L2 > R2 ? L2 : R2;
+                        }
+                        if (!EDGE || lane_act) {
+                            const int4 wq = make_int4(wv4[0], wv4[1], wv4[2], wv4[3]);
+                            if (!wide) *(int4 *)(HG + (j0 & win_mask)) = wq;
+                            *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
+                            if (keep) *(int4 *)(Vrow + c) = wq;
+                        }
+                    };
+                    if (lp || rp) phase2(std::true_type{});
+                    else phase2(std::false_type{});
         POA_MARK("p2_slow");
                 } else if (lane_act) {
                     int wv4[CPT], codev[CPT];
@@ -1238,10 +1304,12 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
             for (int s = 0; s < 8; s++) stamps[(tid ? 64 * 8 : 0) + blockIdx.x * 8 + s] = tacc[s];
     }
     if (tid == 0) {
+        const lead_t L = lead_load();
+        const bool failed = L.failed != 0;
         poa_out &O = outs[blockIdx.x];
-        O.cells = cells;
-        O.vcells = vcells;
-        O.maxw = (uint32_t)maxw;
+        O.cells = L.cells;
+        O.vcells = L.vcells;
+        O.maxw = (uint32_t)L.maxw;
         if (failed) {
             O.status = POA_ST_POOL;
             O.score = POA_NEG;
@@ -1267,7 +1335,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
 static inline size_t poa_pk_lds_bytes(uint32_t hg_cols, uint32_t lds_cols, int nt)
 {
     const int nw = nt / 64;
-    return 4ull * hg_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw) * 16 + 16 + 48 + 16;
+    return 4ull * hg_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw) * 16 + 16 + 48 + 64 + 16;
 }
 
 static inline uint32_t poa_lds_cols(uint32_t max_q) { return ((max_q + 1 + 15u) & ~15u) + 16u; }
@@ -1640,7 +1708,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
                         nb, nt, hg_cols, lds_cols, mw, lds);
 #define POA_ARGS W.d_probs.p + i0, W.d_q.p, W.d_ntab.p, W.d_seq32.p, W.d_preds.p, W.d_sink.p, P, W.d_rows.p, pool_base,      \
                  W.d_next.p + slot, half_pool, W.d_outs.p + i0, lds_cols
-#define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, g1bits
+#define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, (g1bits | (getenv("VGA_POA_DEBUG") ? atoi(getenv("VGA_POA_DEBUG")) << 8 : 0))
             if (packed) {
                 if (getenv("VGA_POA_STAMPS") && nt == 512) {
                     // diagnostic: per-segment cycle shares of the first 64 workgroups (tid 0's wave), printed to stderr
@@ -1656,6 +1724,13 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
                         unsigned long long sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tot = 0;
                         for (int b2 = 0; b2 < 64 && b2 < (int)nb; b2++)
                             for (int s = 0; s < 8; s++) { sum[s] += h_st[wsel * 512 + b2 * 8 + s]; tot += h_st[wsel * 512 + b2 * 8 + s]; }
+                        unsigned long long n_act = 0, n_fast = 0, n_edge = 0;
+                        for (int b2 = 0; b2 < 64 && b2 < (int)nb; b2++) {
+                            const unsigned long long x = h_st[wsel * 512 + b2 * 8 + 7];
+                            n_act += x >> 42; n_fast += x & 0x1fffffull; n_edge += (x >> 21) & 0x1fffffull;
+                        }
+                        fprintf(stderr, "[vga-stamps] wave %d: active wave-steps %llu, fast %llu (of which edge-patched %llu)\n", wsel * 2,
+                                n_act, n_fast, n_edge);
                         fprintf(stderr, "[vga-stamps] wave %d cycles: prologue %llu phase1 %llu (interior: loads %llu) scans %llu step-barrier %llu phase2 %llu row-reduce+barrier %llu (total %llu)\n",
                                 wsel * 2, sum[0], sum[1], sum[6], sum[2], sum[3], sum[4], sum[5], tot);
                     }
