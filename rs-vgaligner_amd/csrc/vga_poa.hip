@@ -665,7 +665,8 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
 //   * node-end value rows in HBM are the same packed words (4 B per cell);
 //   * single-predecessor rows whose predecessor is not the row above ("far") use the lean path as well, with
 //     their five words coming from HBM instead of LDS.
-template <int NT, bool STAMP = false>
+// DEF: the gap penalties are abPOA's defaults (4/2, 24/1 => 3 + 5 bit deltas), known at compile time.
+template <int NT, bool STAMP = false, bool DEF = false>
 __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
     const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
@@ -679,13 +680,15 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // HG is a window of hg_cols columns addressed by (column & win_mask): a power of two smaller than the query when
     // the launch was sized for narrow bands (more workgroups per CU), or every column (win_mask = ~0).
-    int32_t *HG = (int32_t *)smem;                               // [hg_cols] (H << 8) | g
-    uint16_t *Qn = (uint16_t *)(smem + 4ull * hg_cols);          // [lds_cols / 4] four column codes per halfword
-    int4 *sX = (int4 *)(smem + 4ull * hg_cols + ((lds_cols / 2 + 15u) & ~15u));  // [2][NW] {scan1, scan2, last1, last2} per wave
-    int4 *sRed = sX + 2 * NW;         // [NW] {row max, -leftmost, rightmost, 0} per wave
+    // The small exchange structures come first so that their addresses, and HG's, are compile-time constants.
+    int4 *sX = (int4 *)smem;                  // [2][NW] {scan1, scan2, last1, last2} per wave
+    int4 *sRed = sX + 2 * NW;                 // [NW] {row max, -leftmost, rightmost, 0} per wave
     int32_t *edgeW = (int32_t *)(sRed + NW);  // [2] (+2 pad)
     int4 *sRow = (int4 *)(edgeW + 4);         // [3] the row's parameters, written by wave 0 (see the row loop)
     int4 *sLead = sRow + 3;                   // [4] wave 0's allocator state and counters
+    constexpr int HDR = (3 * NW + 1 + 3 + 4) * 16;
+    int32_t *HG = (int32_t *)(smem + HDR);                       // [hg_cols] (H << 8) | g
+    uint16_t *Qn = (uint16_t *)(smem + HDR + 4ull * hg_cols);    // [lds_cols / 4] four column codes per halfword
     const int edge_idx = (int)(edgeW - HG);  // edgeW addressed through HG, see phase 1
 
     const poa_prob pb = probs[blockIdx.x];
@@ -696,9 +699,9 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     const uint32_t *plist = preds + pb.pred0;
     poa_row *R = rows + pb.row0;
 
-    const int g1bits = g1bits_dbg & 255;
+    const int g1bits = DEF ? 3 : (g1bits_dbg & 255);
     const bool dbg_no_fast = (g1bits_dbg >> 8) & 1, dbg_no_edge = (g1bits_dbg >> 9) & 1;  // VGA_POA_DEBUG (diagnostics)
-    const int o1 = P.o1, e1 = P.e1, o2 = P.o2, e2 = P.e2;
+    const int o1 = DEF ? 4 : P.o1, e1 = DEF ? 2 : P.e1, o2 = DEF ? 24 : P.o2, e2 = DEF ? 1 : P.e2;
     const int oe1 = o1 + e1, oe2 = o2 + e2;
     const int g1mask = (1 << g1bits) - 1;
     const int g2w = 8 - g1bits;
@@ -1737,9 +1740,15 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
                 } else {
 #define POA_PK_LAUNCH(T)                                                                                                    \
     case T:                                                                                                                 \
-        chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
-        hipLaunchKernelGGL((k_poa_dp_pk<T>), dim3(nb), dim3(T), lds, st, POA_PK_ARGS);                                     \
+        if (def_pen) {                                                                                                      \
+            chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_poa_dp_pk<T, false, true>), dim3(nb), dim3(T), lds, st, POA_PK_ARGS);                    \
+        } else {                                                                                                            \
+            chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+            hipLaunchKernelGGL((k_poa_dp_pk<T>), dim3(nb), dim3(T), lds, st, POA_PK_ARGS);                                 \
+        }                                                                                                                   \
         break;
+                    const bool def_pen = P.o1 == 4 && P.e1 == 2 && P.o2 == 24 && P.e2 == 1 && !(force && strstr(force, "generic"));
                     switch (nt) {
                         POA_PK_LAUNCH(128) POA_PK_LAUNCH(192) POA_PK_LAUNCH(256) POA_PK_LAUNCH(320)
                         POA_PK_LAUNCH(384) POA_PK_LAUNCH(448) POA_PK_LAUNCH(512)
