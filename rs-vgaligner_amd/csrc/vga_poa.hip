@@ -671,7 +671,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
     const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
     poa_dev_params P, poa_row *rows, uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size,
-    poa_out *__restrict__ outs, uint32_t lds_cols, uint32_t hg_cols, uint32_t win_mask, int g1bits_dbg,
+    poa_out *__restrict__ outs, uint32_t lds_cols, uint32_t hg_cols, uint32_t win_mask, int g1bits_arg,
     unsigned long long *stamps = nullptr)
 {
     constexpr int CPT = 4;
@@ -699,8 +699,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
     const uint32_t *plist = preds + pb.pred0;
     poa_row *R = rows + pb.row0;
 
-    const int g1bits = DEF ? 3 : (g1bits_dbg & 255);
-    const bool dbg_no_fast = (g1bits_dbg >> 8) & 1, dbg_no_edge = (g1bits_dbg >> 9) & 1;  // VGA_POA_DEBUG (diagnostics)
+    const int g1bits = DEF ? 3 : g1bits_arg;
     const int o1 = DEF ? 4 : P.o1, e1 = DEF ? 2 : P.e1, o2 = DEF ? 24 : P.o2, e2 = DEF ? 1 : P.e2;
     const int oe1 = o1 + e1, oe2 = o2 + e2;
     const int g1mask = (1 << g1bits) - 1;
@@ -813,7 +812,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
             else
                 for (int t = 0; t < np; t++) far |= plist[ps + t] != r - 1;
         }
-        if (far) __syncthreads();  // vmcnt(0) + barrier: the value rows / row records of far predecessors have landed
+        if (__builtin_expect(far, 0)) __syncthreads();  // vmcnt(0) + barrier: the value rows / row records of far predecessors have landed
         const bool single = r > 0 && np == 1;   // one predecessor (the row above in LDS, or a far row in HBM)
         const uint32_t sp = first ? ps : r - 1;  // that predecessor
         const bool sp_near = sp == r - 1 && prev_lds;
@@ -936,16 +935,15 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
             const int jw0 = bal + c0 + 64 * CPT * wv, jw1 = jw0 + 64 * CPT - 1;
             const bool lp = jw0 < beg;
             const bool rp = jw1 > end || jw1 > pend;
-            const bool fastw = single && q_plain && wave_act && (lp ? beg : jw0) > pbeg && (!rp || (sp_near && end <= pend + 1)) &&
-                               !dbg_no_fast && !(dbg_no_edge && (lp || rp));
+            const bool fastw = single && q_plain && wave_act && (lp ? beg : jw0) > pbeg && (!rp || (sp_near && end <= pend + 1));
             const int base1 = e1 * j0, base2 = e2 * j0;  // the max-plus scan runs on lane-relative values in the fast path
             if constexpr (STAMP) tacc[7] += (wave_act ? (1ull << 42) : 0ull) + (fastw ? 1ull : 0ull) + ((fastw && (lp || rp)) ? (1ull << 21) : 0ull);
         POA_MARK("p1_fast");
-            if (fastw) {
+            if (__builtin_expect(fastw, 1)) {
                 // ---------------- interior path, phase 1
                 int4 hv;
                 int hprev;
-                if (sp_near) {
+                if (__builtin_expect(sp_near, 1)) {
                     hv = *(const int4 *)(HG + (j0 & win_mask));
                     if (tid == NT - 1) edgeW[buf] = hv.w;
                     // one LDS read through an index (a pointer select would turn into a flat load, which also waits
@@ -1006,7 +1004,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                     agg1 = ag1 + base1;
                     agg2 = ag2 + base2;
                 };
-                if (lp || rp) phase1(std::true_type{});
+                if (__builtin_expect(lp || rp, 0)) phase1(std::true_type{});
                 else phase1(std::false_type{});
         POA_MARK("p1_lean");
             } else if (wave_act && single) {
@@ -1182,7 +1180,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                 int run1 = pre1 > x1 ? pre1 : x1;
                 int run2 = pre2 > x2 ? pre2 : x2;
         POA_MARK("p2_fast");
-                if (fastw) {
+                if (__builtin_expect(fastw, 1)) {
                     // ---------------- interior path, phase 2
                     auto phase2 = [&](auto edge_c) {
                         constexpr bool EDGE = decltype(edge_c)::value;
@@ -1216,7 +1214,7 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                             if (keep) *(int4 *)(Vrow + c) = wq;
                         }
                     };
-                    if (lp || rp) phase2(std::true_type{});
+                    if (__builtin_expect(lp || rp, 0)) phase2(std::true_type{});
                     else phase2(std::false_type{});
         POA_MARK("p2_slow");
                 } else if (lane_act) {
@@ -1248,7 +1246,9 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                     if (!wide) *(int4 *)(HG + (j0 & win_mask)) = wq;
                     *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
                     if (keep) *(int4 *)(Vrow + c) = wq;
-                    if (np > 1) {
+                    if (__builtin_expect(np > 1, 0)) {
+                        int W = (end - bal + 1 + 3) & ~3;  // (recomputed behind a barrier so that the plane addresses are not
+                        asm volatile("" : "+s"(W));       //  hoisted out of the row's step loop into scalar registers)
                         *(uint32_t *)(drow + (uint64_t)W + c) = (uint32_t)(pmeta[0] & 255) | ((uint32_t)(pmeta[1] & 255) << 8) | ((uint32_t)(pmeta[2] & 255) << 16) | ((uint32_t)(pmeta[3] & 255) << 24);
                         *(uint32_t *)(drow + 2ull * W + c) = (uint32_t)((pmeta[0] >> 8) & 255) | ((uint32_t)((pmeta[1] >> 8) & 255) << 8) | ((uint32_t)((pmeta[2] >> 8) & 255) << 16) | ((uint32_t)((pmeta[3] >> 8) & 255) << 24);
                         *(uint32_t *)(drow + 3ull * W + c) = (uint32_t)((pmeta[0] >> 16) & 255) | ((uint32_t)((pmeta[1] >> 16) & 255) << 8) | ((uint32_t)((pmeta[2] >> 16) & 255) << 16) | ((uint32_t)((pmeta[3] >> 16) & 255) << 24);
@@ -1711,7 +1711,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
                         nb, nt, hg_cols, lds_cols, mw, lds);
 #define POA_ARGS W.d_probs.p + i0, W.d_q.p, W.d_ntab.p, W.d_seq32.p, W.d_preds.p, W.d_sink.p, P, W.d_rows.p, pool_base,      \
                  W.d_next.p + slot, half_pool, W.d_outs.p + i0, lds_cols
-#define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, (g1bits | (getenv("VGA_POA_DEBUG") ? atoi(getenv("VGA_POA_DEBUG")) << 8 : 0))
+#define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, g1bits
             if (packed) {
                 if (getenv("VGA_POA_STAMPS") && nt == 512) {
                     // diagnostic: per-segment cycle shares of the first 64 workgroups (tid 0's wave), printed to stderr
