@@ -909,7 +909,6 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
         int carry1 = POA_IDENT, carry2 = POA_IDENT, left1 = POA_IDENT, left2 = POA_IDENT;
         int best = INT32_MIN, lpos = beg, rpos = beg;
         int buf = 0;
-        const unsigned span = (unsigned)(end - beg);
         for (int c0 = 0; c0 < W; c0 += STEP, buf ^= 1) {
             const int c = c0 + CPT * tid;
             const int j0 = bal + c;
@@ -1009,6 +1008,13 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
         POA_MARK("p1_lean");
             } else if (wave_act && single) {
                 // ---------------- lean path, phase 1
+                // Cold path.  Its band limits go through an empty asm so that everything derived from them (spans, masks,
+                // predecessor widths) is computed in here: hoisted out of the step loop it would sit in scalar registers
+                // the hot path is short of, i.e. in v_writelane / v_readlane pairs executed by every wave and row.
+                int pbeg_ = pbeg, pend_ = pend, beg_ = beg, end_ = end, balp_ = balp, gsh_ = gsh;
+                asm volatile("" : "+s"(pbeg_), "+s"(pend_), "+s"(beg_), "+s"(end_), "+s"(balp_), "+s"(gsh_));
+                const int pbeg = pbeg_, pend = pend_, beg = beg_, end = end_, balp = balp_, gsh = gsh_;
+                const unsigned span = (unsigned)(end - beg);
                 int wj[CPT], wm0;
                 const unsigned pspan = (unsigned)(pend - pbeg);
                 if (sp_near) {
@@ -1058,6 +1064,11 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
         POA_MARK("p1_general");
             } else if (wave_act) {
                 // ---------------- general path, phase 1: the source row and rows with several predecessors
+                // (cold path: see the note in the lean path)
+                int beg_ = beg, end_ = end, gsh_ = gsh;
+                asm volatile("" : "+s"(beg_), "+s"(end_), "+s"(gsh_));
+                const int beg = beg_, end = end_, gsh = gsh_;
+                const unsigned span = (unsigned)(end - beg);
                 if (r == 0) {
 #pragma unroll
                     for (int k = 0; k < CPT; k++) ht[k] = (j0 + k == 0) ? 0 : POA_NEG;
@@ -1218,6 +1229,10 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                     else phase2(std::false_type{});
         POA_MARK("p2_slow");
                 } else if (lane_act) {
+                    int beg_ = beg, end_ = end;  // (cold path: see the note in phase 1)
+                    asm volatile("" : "+s"(beg_), "+s"(end_));
+                    const int beg = beg_;
+                    const unsigned span = (unsigned)(end_ - beg_);
                     int wv4[CPT], codev[CPT];
 #pragma unroll
                     for (int k = 0; k < CPT; k++) {
