@@ -1441,7 +1441,8 @@ void poa_prepare(const poa_view &v, poa_prep &g)
     g.ok = true;
 }
 
-struct poa_ws {
+// device + pinned staging of one sub-batch; sub-batches alternate between two of these (and two streams)
+struct poa_slot {
     vga_dbuf<poa_prob> d_probs;
     vga_dbuf<uint4> d_ntab;
     vga_dbuf<uint32_t> d_seq32, d_preds, d_sink, d_orow;
@@ -1449,25 +1450,32 @@ struct poa_ws {
     vga_dbuf<poa_row> d_rows;
     vga_dbuf<poa_out> d_outs;
     vga_dbuf<char> d_q;
-    vga_dbuf<unsigned long long> d_next;
     vga_hbuf<poa_prob> h_probs;
     vga_hbuf<uint4> h_ntab;
-    vga_hbuf<uint32_t> h_seq32, h_preds, h_sink, h_orow;
-    vga_hbuf<uint8_t> h_ops;
-    vga_hbuf<poa_out> h_outs;
+    vga_hbuf<uint32_t> h_seq32, h_preds, h_sink;
     vga_hbuf<char> h_q;
+    // results come back into one of two sets, alternating per use of the slot: the host is still reading set A of the
+    // sub-batch that just finished when the next sub-batch on this slot is enqueued (it will write set B)
+    struct out_set {
+        vga_hbuf<uint32_t> h_orow;
+        vga_hbuf<uint8_t> h_ops;
+        vga_hbuf<poa_out> h_outs;
+    } outs[2];
+    uint32_t uses = 0;
+};
+
+struct poa_ws {
+    poa_slot slot[2];
+    vga_dbuf<unsigned long long> d_next;
     vga_hbuf<unsigned long long> h_next;
     uint8_t *pool = nullptr;
     uint64_t pool_size = 0;
     hipStream_t st2 = nullptr;   // sub-batches alternate between the context's stream and this one
-    hipEvent_t ev_up = nullptr, ev_join = nullptr;
     double pool_scale = 1.0;   // measured pool bytes / estimated bytes, adapted after every sub-batch
     ~poa_ws()
     {
         if (pool) (void)hipFree(pool);
         if (st2) (void)hipStreamDestroy(st2);
-        if (ev_up) (void)hipEventDestroy(ev_up);
-        if (ev_join) (void)hipEventDestroy(ev_join);
     }
 };
 
@@ -1491,10 +1499,10 @@ void parallel_for(uint64_t n, F f) { vga_parallel_for(n, f); }
 
 }  // namespace
 
-int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_params *params, std::vector<poa_item> &out,
-            poa_timing &tm)
+int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vector<poa_item> &out, poa_timing &tm)
 {
-    const uint64_t n = views.size();
+    const uint64_t n = feed.views.size();
+    std::vector<poa_view> &views = feed.views;
     out.assign(n, poa_item());
     tm = poa_timing();
     (void)hipSetDevice(ctx->device);
@@ -1507,19 +1515,13 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "gap penalties: open + extend must be in 0..255 (one byte per gap state)");
     vga_timers_reset(ctx);
     if (n == 0) return VGA_OK;
-
-    // ---- host: node-level graph descriptions (threads over problems)
-    std::vector<poa_prep> G(n);
-    parallel_for(n, [&](uint64_t p) { poa_prepare(views[p], G[p]); });
-    for (uint64_t p = 0; p < n; p++)
-        if (!G[p].ok)
-            return vga_set_error(ctx, VGA_ERR_ARG,
-                                 "POA problem %llu is malformed (no node, empty node, edge with src >= dst, in-degree > 255, "
-                                 "or sequence too long)", (unsigned long long)p);
     uint32_t max_q = 0;
-    for (uint64_t p = 0; p < n; p++) max_q = std::max(max_q, G[p].qlen);
-    const uint32_t lds_cols_all = poa_lds_cols(max_q);
+    for (uint64_t p = 0; p < n; p++) {
+        if (views[p].qlen >= (1u << 24)) return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query %llu too long", (unsigned long long)p);
+        max_q = std::max(max_q, views[p].qlen);
+    }
     {
+        const uint32_t lds_cols_all = poa_lds_cols(max_q);
         int g1b = 0, g2b = 0;
         while ((1 << g1b) <= params->gap_open1 + params->gap_ext1) g1b++;
         while ((1 << g2b) <= params->gap_open2 + params->gap_ext2) g2b++;
@@ -1527,27 +1529,59 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         if (need > 160 * 1024 - 256)
             return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query of %u bases does not fit the LDS-resident POA kernel (limit ~35 kbp, ~22 kbp with large gap penalties)", max_q);
     }
-    tr.mark("node tables (host threads)");
 
-    // ---- flatten into pinned staging (offsets first, then a parallel fill)
+    // ---- launch order and lazy preparation.  The caller may hand the problems over lazily (feed.prepare fills the graph
+    // part of a view on request): then the order is fixed up front from a cheap size proxy and a sub-batch's subgraphs
+    // and node tables are built by the host threads while earlier sub-batches are on the GPU.  Without a proxy every
+    // problem is prepared first and the order is by the footprint estimate (longest first).
+    std::vector<poa_prep> G(n);
     std::vector<poa_prob> probs(n);
-    uint64_t tot_nodes = 0, tot_preds = 0, tot_sink = 0, tot_q = 0, tot_ops = 0, tot_rows = 0, tot_seq = 0;
-    for (uint64_t p = 0; p < n; p++) {
-        poa_prob &pb = probs[p];
+    std::vector<double> est(n, 0.0), estw(n, 0.0);
+    std::vector<uint8_t> ready(n, 0);
+    std::vector<uint32_t> order(n);
+    for (uint64_t p = 0; p < n; p++) order[p] = (uint32_t)p;
+    // Mean band width of a problem.  The band of a row spans from the row maxima to the diagonal qlen - remain, so it
+    // grows with the excess of the longest source-sink path over the query; on 10 kbp reads against DRB1-3123 the mean is
+    // 2w + 1 + 430 + 0.27 * excess (rms error ~25 %).  Only the pool budget and the launch order depend on it, and the
+    // budget scale adapts to the measured footprint after every sub-batch.
+    auto est_width = [&](uint64_t p) -> double {
         const poa_prep &g = G[p];
-        pb.node0 = tot_nodes; pb.pred0 = tot_preds; pb.sink0 = tot_sink; pb.q0 = tot_q; pb.ops0 = tot_ops; pb.row0 = tot_rows;
-        pb.seq0 = tot_seq;
-        pb.n_sink = (uint32_t)g.sinks.size(); pb.qlen = g.qlen; pb.N = g.N; pb.n_nodes = (uint32_t)g.ntab.size(); pb.pad = 0;
-        pb.w = params->wb < 0 ? g.qlen : (uint32_t)((int64_t)params->wb + (int64_t)(params->wf * (double)g.qlen));
-        tot_nodes += g.ntab.size();
-        tot_preds += g.preds.size();
-        tot_sink += g.sinks.size();
-        tot_q += g.qlen;
-        tot_ops += (uint64_t)g.N + g.qlen + 2;
-        tot_rows += (uint64_t)g.N + 1;
-        tot_seq += ((uint64_t)g.N + 3) & ~3ull;
-        out[p].n_rows = g.N;
+        const double w = params->wb < 0 ? (double)g.qlen : (double)params->wb + (double)(uint64_t)(params->wf * (double)g.qlen);
+        double excess = (double)g.longest - (double)g.qlen;
+        if (excess < 0) excess = -excess;
+        return std::min((double)g.qlen + 1.0, 2.0 * w + 1.0 + 430.0 + 0.3 * excess);
+    };
+    bool malformed = false;
+    // prepares launch positions [a, b): the caller's part (subgraphs), then node tables and estimates
+    std::vector<uint32_t> ids;
+    auto ensure = [&](uint64_t a, uint64_t b) {
+        ids.clear();
+        for (uint64_t i = a; i < b && i < n; i++)
+            if (!ready[order[i]]) ids.push_back(order[i]);
+        if (ids.empty()) return;
+        if (feed.prepare) feed.prepare(ids.data(), ids.size());
+        parallel_for(ids.size(), [&](uint64_t t) {
+            const uint32_t p = ids[t];
+            poa_prepare(views[p], G[p]);
+            if (G[p].ok) { estw[p] = est_width(p); est[p] = (double)G[p].N * estw[p] * 2.2; }
+            ready[p] = 1;
+        });
+        for (uint32_t p : ids)
+            if (!G[p].ok) malformed = true;
+    };
+    if (feed.proxy) {
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return feed.proxy[x] > feed.proxy[y]; });
+    } else {
+        ensure(0, n);
+        if (!malformed) std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return est[x] > est[y]; });
     }
+    auto malformed_error = [&]() {
+        return vga_set_error(ctx, VGA_ERR_ARG,
+                             "a POA problem is malformed (no node, empty node, edge with src >= dst, in-degree > 255, or sequence too long)");
+    };
+    if (malformed) return malformed_error();
+    tr.mark("order (+ node tables when not lazy)");
+
     if (!ctx->poa_ws) {
         ctx->poa_ws = new poa_ws();
         ctx->poa_ws_free = [](void *q) { delete (poa_ws *)q; };
@@ -1560,58 +1594,20 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             return vga_set_error(ctx, VGA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
                                  __LINE__);                                                          \
     } while (0)
-    POA_CHECK(W.h_probs.reserve(n)); POA_CHECK(W.h_ntab.reserve(tot_nodes)); POA_CHECK(W.h_seq32.reserve(tot_seq / 4 + 1));
-    POA_CHECK(W.h_preds.reserve(tot_preds + 1)); POA_CHECK(W.h_sink.reserve(tot_sink + 1)); POA_CHECK(W.h_q.reserve(tot_q + 1));
-    POA_CHECK(W.h_ops.reserve(tot_ops)); POA_CHECK(W.h_orow.reserve(tot_ops)); POA_CHECK(W.h_outs.reserve(n));
     POA_CHECK(W.h_next.reserve(2));
-    POA_CHECK(W.d_probs.reserve(n)); POA_CHECK(W.d_ntab.reserve(tot_nodes)); POA_CHECK(W.d_seq32.reserve(tot_seq / 4 + 1));
-    POA_CHECK(W.d_preds.reserve(tot_preds + 1)); POA_CHECK(W.d_sink.reserve(tot_sink + 1)); POA_CHECK(W.d_q.reserve(tot_q + 1));
-    POA_CHECK(W.d_rows.reserve(tot_rows)); POA_CHECK(W.d_outs.reserve(n));
-    POA_CHECK(W.d_ops.reserve(tot_ops)); POA_CHECK(W.d_orow.reserve(tot_ops)); POA_CHECK(W.d_next.reserve(2));
-    tr.mark("reserve");
-    parallel_for(n, [&](uint64_t p) {
-        const poa_prob &pb = probs[p];
-        const poa_prep &g = G[p];
-        memcpy(W.h_ntab.p + pb.node0, g.ntab.data(), g.ntab.size() * sizeof(uint4));
-        if (!g.preds.empty()) memcpy(W.h_preds.p + pb.pred0, g.preds.data(), g.preds.size() * 4);
-        if (!g.sinks.empty()) memcpy(W.h_sink.p + pb.sink0, g.sinks.data(), g.sinks.size() * 4);
-        // node strings of one problem are contiguous in the view
-        memcpy((char *)W.h_seq32.p + pb.seq0, views[p].nodes + views[p].node_off[0], g.N);
-        if (g.qlen) memcpy(W.h_q.p + pb.q0, views[p].query, g.qlen);
-    });
-    tr.mark("fill staging (host threads)");
-
-    // ---- pool sizing and the launch order (longest estimated problem first, so stragglers start early)
-    // Mean band width of a problem.  The band of a row spans from the row maxima to the diagonal qlen - remain, so it
-    // grows with the excess of the longest source-sink path over the query; on 10 kbp reads against DRB1-3123 the mean is
-    // 2w + 1 + 430 + 0.27 * excess (rms error ~25 %).  Only the pool budget and the launch order depend on it, and the
-    // budget scale adapts to the measured footprint after every sub-batch.
-    auto est_width = [&](uint64_t p) -> double {
-        const poa_prep &g = G[p];
-        const double w = params->wb < 0 ? (double)g.qlen : (double)params->wb + (double)(uint64_t)(params->wf * (double)g.qlen);
-        double excess = (double)g.longest - (double)g.qlen;
-        if (excess < 0) excess = -excess;
-        return std::min((double)g.qlen + 1.0, 2.0 * w + 1.0 + 430.0 + 0.3 * excess);
-    };
-    std::vector<double> est(n), estw(n);
-    std::vector<uint32_t> order(n);
-    for (uint64_t p = 0; p < n; p++) { estw[p] = est_width(p); est[p] = (double)G[p].N * estw[p] * 2.2; order[p] = (uint32_t)p; }
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return est[a] > est[b]; });
+    POA_CHECK(W.d_next.reserve(2));
+    // ---- the pool: sized from the first prepared problems, grown generously (a hipMalloc of this size costs seconds)
+    const uint64_t n_probe = std::min<uint64_t>(n, 512);
+    ensure(0, n_probe);
+    if (malformed) return malformed_error();
     {
-        // the traceback output of a sub-batch must be one contiguous slice: number it in launch order
-        uint64_t o = 0;
-        for (uint64_t i = 0; i < n; i++) { probs[order[i]].ops0 = o; o += (uint64_t)G[order[i]].N + G[order[i]].qlen + 2; }
-    }
-    for (uint64_t i = 0; i < n; i++) W.h_probs.p[i] = probs[order[i]];
-    {
-        double want_d = 0;
-        for (uint64_t p = 0; p < n; p++) want_d += est[p] * W.pool_scale * 1.3 + 3.0 * (double)POA_CHUNK;
+        double probe = 0;
+        for (uint64_t i = 0; i < n_probe; i++) probe += est[order[i]];
+        const double want_d = probe / (double)n_probe * (double)n * W.pool_scale * 1.3 + (double)n * 3.0 * (double)POA_CHUNK;
         uint64_t want = (uint64_t)want_d + 64 * POA_CHUNK;
         const char *env_pool = getenv("VGA_POOL_BYTES");
         if (env_pool) want = std::min<uint64_t>(want, strtoull(env_pool, nullptr, 10));
         if (W.pool_size < want) {
-            // grow generously (twice the estimated need) so that the adaptive scale does not trigger re-allocations:
-            // a hipMalloc of this size costs seconds
             size_t free_b = 0, total_b = 0;
             POA_CHECK(hipMemGetInfo(&free_b, &total_b));
             const uint64_t avail = (uint64_t)((double)(free_b + W.pool_size) * 0.85);
@@ -1626,23 +1622,10 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         }
     }
     tr.mark("pool");
-    POA_CHECK(hipMemcpyAsync(W.d_probs.p, W.h_probs.p, n * sizeof(poa_prob), hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(W.d_ntab.p, W.h_ntab.p, tot_nodes * sizeof(uint4), hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(W.d_seq32.p, W.h_seq32.p, tot_seq, hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(W.d_preds.p, W.h_preds.p, tot_preds * 4, hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(W.d_sink.p, W.h_sink.p, tot_sink * 4, hipMemcpyHostToDevice, st));
-    POA_CHECK(hipMemcpyAsync(W.d_q.p, W.h_q.p, tot_q, hipMemcpyHostToDevice, st));
-
     // Two sub-batches are in flight at any time, one per stream, each carving from its own half of the pool: while one
-    // sub-batch drains (its last workgroups, then the latency-bound traceback and the copies back) the other one's
+    // drains (its last workgroups, then the latency-bound traceback and the copies back) the other one's
     // workgroups fill the CUs.
-    if (!W.st2) {
-        POA_CHECK(hipStreamCreateWithFlags(&W.st2, hipStreamNonBlocking));
-        POA_CHECK(hipEventCreateWithFlags(&W.ev_up, hipEventDisableTiming));
-        POA_CHECK(hipEventCreateWithFlags(&W.ev_join, hipEventDisableTiming));
-    }
-    POA_CHECK(hipEventRecord(W.ev_up, st));
-    POA_CHECK(hipStreamWaitEvent(W.st2, W.ev_up, 0));
+    if (!W.st2) POA_CHECK(hipStreamCreateWithFlags(&W.st2, hipStreamNonBlocking));
     hipStream_t sarr[2] = {st, W.st2};
     const uint64_t half_pool = (W.pool_size / 2) & ~(POA_CHUNK - 1);
 
@@ -1652,24 +1635,76 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
 
     bool packed_all = true;  // value rows are 4 B per cell with the packed kernel, 6 B otherwise (byte model)
     int t_total = vga_timer_begin(ctx, "poa_total", 0);
-    struct sub_t { uint64_t i0, i1; double raw_est; int slot; };
+    struct sub_t { uint64_t i0, i1; double raw_est; int slot; int oset; };
     hipError_t launch_err = hipSuccess;
-    // enqueue DP + traceback + result copies of a sub-batch that starts at launch position i0 and ends at cap at the latest
+    uint64_t in_flight_other = 0;  // problems of the sub-batch on the other stream (they share the GPU with this launch)
+    // stage, upload and enqueue DP + traceback + result copies of a sub-batch that starts at launch position i0 and ends
+    // at cap at the latest
     auto launch = [&](uint64_t i0, uint64_t cap, int slot) -> sub_t {
         hipStream_t st = sarr[slot];  // shadows the context's stream inside this lambda
+        poa_slot &S = W.slot[slot];
         uint8_t *pool_base = W.pool + (uint64_t)slot * half_pool;
         const double budget = (double)half_pool * 0.92;
         double used_est = 0, raw_est = 0;
         uint64_t i1 = i0;
         while (i1 < cap) {
+            if (!ready[order[i1]]) ensure(i1, std::min<uint64_t>(cap, i1 + 256));
+            if (malformed) break;
             const double e = est[order[i1]] * W.pool_scale + 3.0 * (double)POA_CHUNK;
             if (i1 > i0 && used_est + e > budget) break;
             used_est += e;
             raw_est += est[order[i1]];
             i1++;
         }
-        const uint32_t nb = (uint32_t)(i1 - i0);
         auto chk = [&](hipError_t e) { if (e != hipSuccess && launch_err == hipSuccess) launch_err = e; };
+        if (malformed || i1 == i0) return {i0, i0, 0.0, slot, 0};
+        const int oset = (int)(S.uses++ & 1u);
+        poa_slot::out_set &O = S.outs[oset];
+        const uint32_t nb = (uint32_t)(i1 - i0);
+        // offsets of the sub-batch's problems inside this slot's buffers
+        uint64_t tot_nodes = 0, tot_preds = 0, tot_sink = 0, tot_q = 0, tot_ops = 0, tot_rows = 0, tot_seq = 0;
+        for (uint64_t i = i0; i < i1; i++) {
+            const uint32_t p = order[i];
+            poa_prob &pb = probs[p];
+            const poa_prep &g = G[p];
+            pb.node0 = tot_nodes; pb.pred0 = tot_preds; pb.sink0 = tot_sink; pb.q0 = tot_q; pb.ops0 = tot_ops; pb.row0 = tot_rows;
+            pb.seq0 = tot_seq;
+            pb.n_sink = (uint32_t)g.sinks.size(); pb.qlen = g.qlen; pb.N = g.N; pb.n_nodes = (uint32_t)g.ntab.size(); pb.pad = 0;
+            pb.w = params->wb < 0 ? g.qlen : (uint32_t)((int64_t)params->wb + (int64_t)(params->wf * (double)g.qlen));
+            tot_nodes += g.ntab.size();
+            tot_preds += g.preds.size();
+            tot_sink += g.sinks.size();
+            tot_q += g.qlen;
+            tot_ops += (uint64_t)g.N + g.qlen + 2;
+            tot_rows += (uint64_t)g.N + 1;
+            tot_seq += ((uint64_t)g.N + 3) & ~3ull;
+            out[p].n_rows = g.N;
+        }
+        chk(S.h_probs.reserve(nb)); chk(S.h_ntab.reserve(tot_nodes)); chk(S.h_seq32.reserve(tot_seq / 4 + 1));
+        chk(S.h_preds.reserve(tot_preds + 1)); chk(S.h_sink.reserve(tot_sink + 1)); chk(S.h_q.reserve(tot_q + 1));
+        chk(O.h_ops.reserve(tot_ops)); chk(O.h_orow.reserve(tot_ops)); chk(O.h_outs.reserve(nb));
+        chk(S.d_probs.reserve(nb)); chk(S.d_ntab.reserve(tot_nodes)); chk(S.d_seq32.reserve(tot_seq / 4 + 1));
+        chk(S.d_preds.reserve(tot_preds + 1)); chk(S.d_sink.reserve(tot_sink + 1)); chk(S.d_q.reserve(tot_q + 1));
+        chk(S.d_rows.reserve(tot_rows)); chk(S.d_outs.reserve(nb)); chk(S.d_ops.reserve(tot_ops)); chk(S.d_orow.reserve(tot_ops));
+        if (launch_err != hipSuccess) return {i0, i0, 0.0, slot, 0};
+        parallel_for(nb, [&](uint64_t t) {
+            const uint32_t p = order[i0 + t];
+            const poa_prob &pb = probs[p];
+            const poa_prep &g = G[p];
+            S.h_probs.p[t] = pb;
+            memcpy(S.h_ntab.p + pb.node0, g.ntab.data(), g.ntab.size() * sizeof(uint4));
+            if (!g.preds.empty()) memcpy(S.h_preds.p + pb.pred0, g.preds.data(), g.preds.size() * 4);
+            if (!g.sinks.empty()) memcpy(S.h_sink.p + pb.sink0, g.sinks.data(), g.sinks.size() * 4);
+            // node strings of one problem are contiguous in the view
+            memcpy((char *)S.h_seq32.p + pb.seq0, views[p].nodes + views[p].node_off[0], g.N);
+            if (g.qlen) memcpy(S.h_q.p + pb.q0, views[p].query, g.qlen);
+        });
+        chk(hipMemcpyAsync(S.d_probs.p, S.h_probs.p, nb * sizeof(poa_prob), hipMemcpyHostToDevice, st));
+        chk(hipMemcpyAsync(S.d_ntab.p, S.h_ntab.p, tot_nodes * sizeof(uint4), hipMemcpyHostToDevice, st));
+        chk(hipMemcpyAsync(S.d_seq32.p, S.h_seq32.p, tot_seq, hipMemcpyHostToDevice, st));
+        chk(hipMemcpyAsync(S.d_preds.p, S.h_preds.p, tot_preds * 4, hipMemcpyHostToDevice, st));
+        chk(hipMemcpyAsync(S.d_sink.p, S.h_sink.p, tot_sink * 4, hipMemcpyHostToDevice, st));
+        chk(hipMemcpyAsync(S.d_q.p, S.h_q.p, tot_q, hipMemcpyHostToDevice, st));
         chk(hipMemsetAsync(W.d_next.p + slot, 0, sizeof(unsigned long long), st));
         int t_dp = vga_timer_begin(ctx, "poa_band_dp", 0, st);
         {
@@ -1706,7 +1741,7 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
                 size_t best_waves = 0;
                 for (int t = 128; t <= 512; t += 64) {
                     const size_t per_cu = std::min<size_t>(by_lds(t), (size_t)(28 / (t / 64)));
-                    const size_t waves = std::min<size_t>(n - i0, per_cu * (size_t)ctx->n_cu) * (size_t)(t / 64);
+                    const size_t waves = std::min<size_t>(n - i0 + in_flight_other, per_cu * (size_t)ctx->n_cu) * (size_t)(t / 64);
                     if (waves > best_waves) { best_waves = waves; nt = t; }
                 }
                 const char *ent = getenv("VGA_POA_NT");
@@ -1724,8 +1759,8 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
             if (tr.on)
                 fprintf(stderr, "[vga-trace] poa: launch %u problems, NT %d, window %u of %u columns, widest estimate %.0f, LDS %zu B\n",
                         nb, nt, hg_cols, lds_cols, mw, lds);
-#define POA_ARGS W.d_probs.p + i0, W.d_q.p, W.d_ntab.p, W.d_seq32.p, W.d_preds.p, W.d_sink.p, P, W.d_rows.p, pool_base,      \
-                 W.d_next.p + slot, half_pool, W.d_outs.p + i0, lds_cols
+#define POA_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_sink.p, P, S.d_rows.p, pool_base,          \
+                 W.d_next.p + slot, half_pool, S.d_outs.p, lds_cols
 #define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, g1bits
             if (packed) {
                 if (getenv("VGA_POA_STAMPS") && nt == 512) {
@@ -1787,22 +1822,20 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         }
         vga_timer_end(ctx, t_dp);
         int t_tb = vga_timer_begin(ctx, "poa_traceback", 0, st);
-        hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, W.d_probs.p + i0, W.d_rows.p, W.d_preds.p,
-                           pool_base, W.d_outs.p + i0, W.d_ops.p, W.d_orow.p);
+        hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
+                           pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p);
         vga_timer_end(ctx, t_tb);
-        const uint64_t o0 = probs[order[i0]].ops0;
-        const uint64_t o1 = i1 < n ? probs[order[i1]].ops0 : tot_ops;
-        chk(hipMemcpyAsync(W.h_outs.p + i0, W.d_outs.p + i0, nb * sizeof(poa_out), hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(O.h_outs.p, S.d_outs.p, nb * sizeof(poa_out), hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(W.h_next.p + slot, W.d_next.p + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        chk(hipMemcpyAsync(W.h_ops.p + o0, W.d_ops.p + o0, o1 - o0, hipMemcpyDeviceToHost, st));
-        chk(hipMemcpyAsync(W.h_orow.p + o0, W.d_orow.p + o0, (o1 - o0) * 4, hipMemcpyDeviceToHost, st));
-        return {i0, i1, raw_est, slot};
+        chk(hipMemcpyAsync(O.h_ops.p, S.d_ops.p, tot_ops, hipMemcpyDeviceToHost, st));
+        chk(hipMemcpyAsync(O.h_orow.p, S.d_orow.p, tot_ops * 4, hipMemcpyDeviceToHost, st));
+        return {i0, i1, raw_est, slot, oset};
     };
     // host: CIGAR / cs / node path of one problem from the raw op stream (reverse order on the device)
-    auto post_one = [&](uint64_t i) {
+    auto post_one = [&](const poa_slot::out_set &S, uint64_t i0, uint64_t i) {
         const uint32_t p = order[i];
         poa_item &it = out[p];
-        const poa_out &ho = W.h_outs.p[i];
+        const poa_out &ho = S.h_outs.p[i - i0];
         it.ok = ho.status == POA_ST_OK ? 1 : 0;
         it.score = ho.score;
         it.n_cells = ho.cells;
@@ -1810,8 +1843,8 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         if (!it.ok) return;
         const poa_prep &g = G[p];
         const poa_prob &pb = probs[p];
-        const uint8_t *po = W.h_ops.p + pb.ops0;
-        const uint32_t *pr = W.h_orow.p + pb.ops0;
+        const uint8_t *po = S.h_ops.p + pb.ops0;
+        const uint32_t *pr = S.h_orow.p + pb.ops0;
         const char *q = views[p].query;
         const char *bases = views[p].nodes + views[p].node_off[0];  // row r is bases[r - 1]
         const uint32_t nops = ho.nops;
@@ -1868,18 +1901,22 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         }
     };
     // Software pipeline.  `todo` holds the launch-order ranges still to be enqueued (a sub-batch that overflowed its pool
-    // half goes back to the front); up to two sub-batches are in flight, one per stream; the host threads turn a finished
-    // sub-batch's op streams into CIGAR / cs strings while the GPU works on the next two.
+    // half goes back to the front); up to two sub-batches are in flight, one per stream.  While the GPU works on them the
+    // host threads prepare the problems of the next sub-batch (the caller's subgraphs, node tables) and turn the op
+    // streams of the sub-batch that just finished into CIGAR / cs strings.
     int rc_final = VGA_OK;
     std::vector<std::pair<uint64_t, uint64_t>> todo;  // used as a stack of [begin, end) ranges, front = back()
     todo.push_back({0, n});
     std::vector<sub_t> inflight;
     bool slot_busy[2] = {false, false};
+    uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
     auto fill = [&]() {
-        while (inflight.size() < 2 && !todo.empty()) {
+        while (inflight.size() < 2 && !todo.empty() && !malformed && launch_err == hipSuccess) {
             const int slot = slot_busy[0] ? 1 : 0;
             auto &seg = todo.back();
+            in_flight_other = inflight.empty() ? 0 : inflight.front().i1 - inflight.front().i0;
             sub_t sb = launch(seg.first, seg.second, slot);
+            if (sb.i1 == sb.i0) break;
             if (sb.i1 >= seg.second) todo.pop_back();
             else seg.first = sb.i1;
             slot_busy[slot] = true;
@@ -1888,16 +1925,18 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
     };
     fill();
     while (!inflight.empty()) {
+        // look ahead: prepare the problems the next launch will start with while the GPU is busy
+        if (!todo.empty()) ensure(todo.back().first, std::min<uint64_t>(todo.back().second, todo.back().first + 1536));
         const sub_t cur = inflight.front();
         inflight.erase(inflight.begin());
         POA_CHECK(hipStreamSynchronize(sarr[cur.slot]));
-        slot_busy[cur.slot] = false;
-        if (launch_err != hipSuccess)
-            return vga_set_error(ctx, VGA_ERR_HIP, "POA launch failed: %s", hipGetErrorString(launch_err));
+        const poa_slot::out_set &S = W.slot[cur.slot].outs[cur.oset];
+        if (launch_err != hipSuccess) break;
         bool pool_fail = false;
         for (uint64_t i = cur.i0; i < cur.i1; i++)
-            if (W.h_outs.p[i].status == POA_ST_POOL) pool_fail = true;
+            if (S.h_outs.p[i - cur.i0].status == POA_ST_POOL) pool_fail = true;
         if (pool_fail) {
+            slot_busy[cur.slot] = false;
             if (cur.i1 - cur.i0 == 1 && W.pool_scale >= 8.0) { rc_final = VGA_ERR_POOL; break; }
             W.pool_scale = std::min(16.0, W.pool_scale * 1.7);
             todo.push_back({cur.i0, cur.i1});  // enqueue it again, in smaller pieces
@@ -1906,69 +1945,49 @@ int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_para
         }
         if (cur.raw_est > 0) {
             const double ratio = (double)W.h_next.p[cur.slot] / cur.raw_est;
+            // conservative on purpose: a sub-batch that overflows its half takes its unfinished problems down with it
             W.pool_scale = std::max(ratio * 1.15, 0.6 * W.pool_scale + 0.4 * ratio * 1.25);
         }
         if (tr.on) {
             double worst = 0;
             uint32_t mx = 0;
             for (uint64_t i = cur.i0; i < cur.i1; i++) {
-                worst = std::max(worst, (double)W.h_outs.p[i].maxw / estw[order[i]]);
-                mx = std::max(mx, W.h_outs.p[i].maxw);
+                worst = std::max(worst, (double)S.h_outs.p[i - cur.i0].maxw / estw[order[i]]);
+                mx = std::max(mx, S.h_outs.p[i - cur.i0].maxw);
             }
             fprintf(stderr, "[vga-trace] poa: sub-batch [%llu, %llu) done, pool %.1f GB, widest row %u columns, worst width / estimate %.3f\n",
                     (unsigned long long)cur.i0, (unsigned long long)cur.i1, (double)W.h_next.p[cur.slot] / 1e9, mx, worst);
-            const char *dump = getenv("VGA_POA_DUMP_WIDTHS");
-            if (dump) {
-                FILE *f = fopen(dump, "a");
-                if (f) {
-                    for (uint64_t i = cur.i0; i < cur.i1; i++)
-                        fprintf(f, "%u %u %d %.0f %u %llu\n", G[order[i]].N, G[order[i]].qlen, G[order[i]].longest, estw[order[i]],
-                                W.h_outs.p[i].maxw, (unsigned long long)W.h_outs.p[i].cells);
-                    fclose(f);
-                }
-            }
         }
-        fill();  // keep the GPU busy before the host-side post-processing of this sub-batch
+        // refill the GPU first (the new sub-batch's results go to the slot's other result set), then post-process
+        slot_busy[cur.slot] = false;
+        fill();
         {
             const uint64_t a0 = cur.i0, cnt = cur.i1 - cur.i0;
-            parallel_for(cnt, [&](uint64_t t) { post_one(a0 + t); });
+            parallel_for(cnt, [&](uint64_t t) { post_one(S, a0, a0 + t); });
+            for (uint64_t i = cur.i0; i < cur.i1; i++) {
+                const poa_out &ho = S.h_outs.p[i - cur.i0];
+                all_cells += ho.cells; all_vcells += ho.vcells; all_ops += ho.nops;
+                all_rows += G[order[i]].N; all_q += G[order[i]].qlen;
+            }
         }
     }
-    // join the second stream into the context's stream (the caller only synchronises that one)
-    POA_CHECK(hipEventRecord(W.ev_join, W.st2));
-    POA_CHECK(hipStreamWaitEvent(st, W.ev_join, 0));
+    // drain both streams (also on the error paths: the slots belong to the context)
+    (void)hipStreamSynchronize(W.st2);
+    (void)hipStreamSynchronize(st);
+    if (launch_err != hipSuccess) return vga_set_error(ctx, VGA_ERR_HIP, "POA launch failed: %s", hipGetErrorString(launch_err));
+    if (malformed) return malformed_error();
     vga_timer_end(ctx, t_total);
     tr.mark("dp + traceback + cigar (pipelined sub-batches)");
-    if (rc_final != VGA_OK) {
-        (void)hipStreamSynchronize(W.st2);
-        (void)hipStreamSynchronize(st);
-    }
     if (rc_final != VGA_OK)
         return vga_set_error(ctx, rc_final, "a single POA problem does not fit the %llu byte traceback pool",
                              (unsigned long long)W.pool_size);
     POA_CHECK(hipStreamSynchronize(st));
     vga_timers_collect(ctx);
     // byte model of the DP kernel: graph bases + query + 1 direction byte per cell
-    // + the value rows of node-end bases (4 B per cell packed, 6 B otherwise), written once and read back at least once
-    uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
-    for (uint64_t i = 0; i < n; i++) {
-        all_cells += W.h_outs.p[i].cells; all_vcells += W.h_outs.p[i].vcells; all_ops += W.h_outs.p[i].nops;
-        all_rows += G[i].N; all_q += G[i].qlen;
-    }
+    // + the value rows kept in HBM (4 B per cell packed, 6 B otherwise), written once and read back at least once
     for (auto &a : ctx->last_times) {
         if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + (packed_all ? 8 : 12) * all_vcells;
         if (a.name == "poa_traceback") a.bytes = 6 * all_ops;
-    }
-    if (tr.on) {
-        // mean band width per problem (cells / rows), 256-column buckets
-        uint32_t hist[17] = {0};
-        for (uint64_t i = 0; i < n; i++) {
-            const uint64_t wmean = W.h_outs.p[i].cells / (G[order[i]].N ? G[order[i]].N : 1);
-            hist[std::min<uint64_t>(wmean / 256, 16)]++;
-        }
-        fprintf(stderr, "[vga-trace] poa: mean band width histogram (256-column buckets):");
-        for (int b = 0; b < 17; b++) fprintf(stderr, " %u", hist[b]);
-        fprintf(stderr, "\n");
     }
     tm.ms_dp = vga_timer_sum(ctx, "poa_band_dp");
     tm.ms_tb = vga_timer_sum(ctx, "poa_traceback");
@@ -1994,7 +2013,9 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     if (!ctx || !out || !params || (n && (!node_ptr || !node_off || !nodes_concat || !edge_ptr || !query_off || !queries_concat)))
         return VGA_ERR_ARG;
     *out = nullptr;
-    std::vector<poa_view> views(n);
+    poa_feed feed;
+    std::vector<poa_view> &views = feed.views;
+    views.resize(n);
     for (uint64_t p = 0; p < n; p++) {
         const uint64_t ql = query_off[p + 1] - query_off[p];
         if (ql >= (1ull << 24)) return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query %llu too long", (unsigned long long)p);
@@ -2003,7 +2024,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     }
     std::vector<poa_item> items;
     poa_timing tm;
-    int rc = poa_run(ctx, views, params, items, tm);
+    int rc = poa_run(ctx, feed, params, items, tm);
     if (rc != VGA_OK) return rc;
     vga_poa_result *res = (vga_poa_result *)calloc(1, sizeof(vga_poa_result));
     res->n = n;

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -33,7 +34,16 @@ struct poa_timing {
     float ms_dp = 0, ms_tb = 0, ms_total = 0;
 };
 
+// How poa_run obtains its problems.  `views` has one entry per problem with query / qlen valid.  When `prepare` is
+// set the graph part of a view (nodes, edges) is filled on request, for the listed problems, shortly before they are
+// staged -- poa_run calls it while earlier sub-batches are on the GPU -- and `proxy` (one value per problem, larger
+// = bigger) fixes the launch order up front.  Without `prepare` every view is complete and the order is by footprint.
+struct poa_feed {
+    std::vector<poa_view> views;
+    std::function<void(const uint32_t *ids, uint64_t cnt)> prepare;
+    const double *proxy = nullptr;
+};
+
 // Runs every problem on the GPU (sub-batched to fit the pool).  Returns VGA_OK or a negative VGA_ERR_*.
-int poa_run(vga_ctx *ctx, const std::vector<poa_view> &views, const vga_poa_params *params, std::vector<poa_item> &out,
-            poa_timing &tm);
+int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vector<poa_item> &out, poa_timing &tm);
 
