@@ -666,15 +666,18 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
 //   * single-predecessor rows whose predecessor is not the row above ("far") use the lean path as well, with
 //     their five words coming from HBM instead of LDS.
 // DEF: the gap penalties are abPOA's defaults (4/2, 24/1 => 3 + 5 bit deltas), known at compile time.
-template <int NT, bool STAMP = false, bool DEF = false>
-__global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
+// CPT: columns per lane and step (4 or 8).  Eight halve the per-lane-step overhead (wave scan, cross-wave exchange, address
+// arithmetic) per cell but need ~22 more vector registers (five waves per SIMD instead of seven); measured on config 3 the
+// instruction count per cell does not drop and the step is 3 % slower, so only CPT = 4 is instantiated.
+template <int NT, bool STAMP = false, bool DEF = false, int CPT = 4>
+__global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
     const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
     const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
     poa_dev_params P, poa_row *rows, uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size,
     poa_out *__restrict__ outs, uint32_t lds_cols, uint32_t hg_cols, uint32_t win_mask, int g1bits_arg,
     unsigned long long *stamps = nullptr)
 {
-    constexpr int CPT = 4;
+    constexpr int QPT = CPT / 4;  // quads (one LDS int4 / one direction dword each) per lane and step
     constexpr int NW = NT / 64;
     constexpr int STEP = NT * CPT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -918,10 +921,13 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
             // carried from phase 1 to phase 2, per cell: ht and  meta = hts | ofl << 2 | u1 << 8 | u2 << 16
             int ht[CPT], meta[CPT], pmeta[CPT];
             int agg1 = POA_IDENT, agg2 = POA_IDENT, alast1 = POA_IDENT, alast2 = POA_IDENT;
-            int wold[CPT];  // this lane's LDS words (their low byte is rewritten together with H)
 #pragma unroll
-            for (int k = 0; k < CPT; k++) { ht[k] = POA_NEG; meta[k] = (o1 << 8) | (o2 << 16); pmeta[k] = 0; wold[k] = 0; }
-            const uint32_t qn = wave_act ? (uint32_t)Qn[j0 >> 2] : 0u;
+            for (int k = 0; k < CPT; k++) { ht[k] = POA_NEG; meta[k] = (o1 << 8) | (o2 << 16); pmeta[k] = 0; }
+            uint32_t qn = 0u;  // one-hot code nibbles of this lane's columns
+            if (wave_act) {
+#pragma unroll
+                for (int q = 0; q < QPT; q++) qn |= (uint32_t)Qn[(j0 >> 2) + q] << (16 * q);
+            }
             // Fast path of a single-predecessor row (every query base A/C/G/T): no per-cell band masks.  It needs every
             // ACTIVE cell of the wave, and the column to its left, inside the predecessor's band.  Two cheap patches let
             // the band's edge waves take it too:
@@ -940,29 +946,35 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
         POA_MARK("p1_fast");
             if (__builtin_expect(fastw, 1)) {
                 // ---------------- interior path, phase 1
-                int4 hv;
+                int4 hv[QPT];
                 int hprev;
                 if (__builtin_expect(sp_near, 1)) {
-                    hv = *(const int4 *)(HG + (j0 & win_mask));
-                    if (tid == NT - 1) edgeW[buf] = hv.w;
+#pragma unroll
+                    for (int q = 0; q < QPT; q++) hv[q] = *(const int4 *)(HG + ((j0 + 4 * q) & win_mask));
+                    if (tid == NT - 1) edgeW[buf] = hv[QPT - 1].w;
                     // one LDS read through an index (a pointer select would turn into a flat load, which also waits
                     // for the outstanding global stores)
                     hprev = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : ((j0 > 0 ? j0 - 1 : 0) & win_mask)];
                     asm volatile("" : "+v"(hprev));
                     hprev >>= 8;
                 } else {
-                    hv = *(const int4 *)(Vp + (j0 - balp));
+#pragma unroll
+                    for (int q = 0; q < QPT; q++) hv[q] = *(const int4 *)(Vp + (j0 - balp) + 4 * q);
                     hprev = Vp[j0 - balp > 0 ? j0 - balp - 1 : 0];
                     // consume the loads inside this branch: otherwise their s_waitcnt vmcnt lands in the code shared
                     // with near rows, where it would also wait for every outstanding direction / value store
-                    asm volatile("" : "+v"(hv.x), "+v"(hv.y), "+v"(hv.z), "+v"(hv.w), "+v"(hprev));
+#pragma unroll
+                    for (int q = 0; q < QPT; q++) asm volatile("" : "+v"(hv[q].x), "+v"(hv[q].y), "+v"(hv[q].z), "+v"(hv[q].w));
+                    asm volatile("" : "+v"(hprev));
                     hprev >>= 8;
                 }
                 stamp(6);
                 // the pure interior variant and the edge variant (with the lp / rp patches) are separate instantiations
                 auto phase1 = [&](auto edge_c) {
                     constexpr bool EDGE = decltype(edge_c)::value;
-                    int wj[CPT] = {hv.x, hv.y, hv.z, hv.w};
+                    int wj[CPT];
+#pragma unroll
+                    for (int q = 0; q < QPT; q++) { wj[4 * q] = hv[q].x; wj[4 * q + 1] = hv[q].y; wj[4 * q + 2] = hv[q].z; wj[4 * q + 3] = hv[q].w; }
                     if constexpr (EDGE) {
                         if (rp) {
 #pragma unroll
@@ -1018,20 +1030,29 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                 int wj[CPT], wm0;
                 const unsigned pspan = (unsigned)(pend - pbeg);
                 if (sp_near) {
-                    const int4 hv = *(const int4 *)(HG + (j0 & win_mask));
-                    wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
-                    if (tid == NT - 1) edgeW[buf] = hv.w;
+#pragma unroll
+                    for (int q = 0; q < QPT; q++) {
+                        const int4 hv = *(const int4 *)(HG + ((j0 + 4 * q) & win_mask));
+                        wj[4 * q] = hv.x; wj[4 * q + 1] = hv.y; wj[4 * q + 2] = hv.z; wj[4 * q + 3] = hv.w;
+                    }
+                    if (tid == NT - 1) edgeW[buf] = wj[CPT - 1];
                     const int jm1 = j0 > 0 ? j0 - 1 : 0;
                     wm0 = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : (jm1 & win_mask)];
                     asm volatile("" : "+v"(wm0));
                 } else {
                     const int idx = j0 - balp;
                     const int Wp = (pend - balp + 1 + 3) & ~3;
-                    int4 hv = make_int4(0, 0, 0, 0);
-                    if (idx >= 0 && idx < Wp) hv = *(const int4 *)(Vp + idx);
-                    wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
+#pragma unroll
+                    for (int q = 0; q < QPT; q++) {
+                        int4 hv = make_int4(0, 0, 0, 0);
+                        if (idx + 4 * q >= 0 && idx + 4 * q < Wp) hv = *(const int4 *)(Vp + idx + 4 * q);
+                        wj[4 * q] = hv.x; wj[4 * q + 1] = hv.y; wj[4 * q + 2] = hv.z; wj[4 * q + 3] = hv.w;
+                    }
                     wm0 = (idx >= 1 && idx - 1 < Wp) ? Vp[idx - 1] : 0;
-                    asm volatile("" : "+v"(wj[0]), "+v"(wj[1]), "+v"(wj[2]), "+v"(wj[3]), "+v"(wm0));  // wait here, not in shared code
+                    // wait here, not in shared code
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) asm volatile("" : "+v"(wj[k]));
+                    asm volatile("" : "+v"(wm0));
                 }
                 bool inprev = j0 >= 1 && (unsigned)(j0 - 1 - pbeg) <= pspan;
 #pragma unroll
@@ -1082,9 +1103,12 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                         int bp, ep;
                         if (p == r - 1 && prev_lds) {
                             bp = prev_beg; ep = prev_end;
-                            const int4 hv = *(const int4 *)(HG + (j0 & win_mask));
-                            wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
-                            if (tid == NT - 1) edgeW[buf] = hv.w;
+#pragma unroll
+                            for (int q = 0; q < QPT; q++) {
+                                const int4 hv = *(const int4 *)(HG + ((j0 + 4 * q) & win_mask));
+                                wj[4 * q] = hv.x; wj[4 * q + 1] = hv.y; wj[4 * q + 2] = hv.z; wj[4 * q + 3] = hv.w;
+                            }
+                            if (tid == NT - 1) edgeW[buf] = wj[CPT - 1];
                             const int jm1 = j0 > 0 ? j0 - 1 : 0;
                             wm0 = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : (jm1 & win_mask)];
                             asm volatile("" : "+v"(wm0));
@@ -1098,11 +1122,17 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                             const int balq = bp & ~3;
                             const int Wq = (ep - balq + 1 + 3) & ~3;
                             const int idx = j0 - balq;
-                            int4 hv = make_int4(0, 0, 0, 0);
-                            if (idx >= 0 && idx < Wq) hv = *(const int4 *)(Vq + idx);
-                            wj[0] = hv.x; wj[1] = hv.y; wj[2] = hv.z; wj[3] = hv.w;
+#pragma unroll
+                            for (int q = 0; q < QPT; q++) {
+                                int4 hv = make_int4(0, 0, 0, 0);
+                                if (idx + 4 * q >= 0 && idx + 4 * q < Wq) hv = *(const int4 *)(Vq + idx + 4 * q);
+                                wj[4 * q] = hv.x; wj[4 * q + 1] = hv.y; wj[4 * q + 2] = hv.z; wj[4 * q + 3] = hv.w;
+                            }
                             wm0 = (idx >= 1 && idx - 1 < Wq) ? Vq[idx - 1] : 0;
-                            asm volatile("" : "+v"(wj[0]), "+v"(wj[1]), "+v"(wj[2]), "+v"(wj[3]), "+v"(wm0));  // wait here, not in shared code
+                            // wait here, not in shared code
+#pragma unroll
+                            for (int k = 0; k < CPT; k++) asm volatile("" : "+v"(wj[k]));
+                            asm volatile("" : "+v"(wm0));
                         }
                         const unsigned pspan = (unsigned)(ep - bp);
 #pragma unroll
@@ -1218,11 +1248,15 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                             R1 = L1 > R1 ? L1 : R1;
                             R2 = L2 > R2 ? L2 : R2;
                         }
-                        if (!EDGE || lane_act) {
-                            const int4 wq = make_int4(wv4[0], wv4[1], wv4[2], wv4[3]);
-                            if (!wide) *(int4 *)(HG + (j0 & win_mask)) = wq;
-                            *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
-                            if (keep) *(int4 *)(Vrow + c) = wq;
+#pragma unroll
+                        for (int q = 0; q < QPT; q++) {
+                            if (!EDGE || j0 + 4 * q <= end) {
+                                const int4 wq = make_int4(wv4[4 * q], wv4[4 * q + 1], wv4[4 * q + 2], wv4[4 * q + 3]);
+                                if (!wide) *(int4 *)(HG + ((j0 + 4 * q) & win_mask)) = wq;
+                                *(uint32_t *)(drow + c + 4 * q) = (uint32_t)codev[4 * q] | ((uint32_t)codev[4 * q + 1] << 8) |
+                                                                 ((uint32_t)codev[4 * q + 2] << 16) | ((uint32_t)codev[4 * q + 3] << 24);
+                                if (keep) *(int4 *)(Vrow + c + 4 * q) = wq;
+                            }
                         }
                     };
                     if (__builtin_expect(lp || rp, 0)) phase2(std::true_type{});
@@ -1257,16 +1291,23 @@ __global__ __launch_bounds__(NT, 7) void k_poa_dp_pk(
                         run2 = a2 > run2 ? a2 : run2;
                         la1 = actk ? a1 : la1; la2 = actk ? a2 : la2;
                     }
-                    const int4 wq = make_int4(wv4[0], wv4[1], wv4[2], wv4[3]);
-                    if (!wide) *(int4 *)(HG + (j0 & win_mask)) = wq;
-                    *(uint32_t *)(drow + c) = (uint32_t)codev[0] | ((uint32_t)codev[1] << 8) | ((uint32_t)codev[2] << 16) | ((uint32_t)codev[3] << 24);
-                    if (keep) *(int4 *)(Vrow + c) = wq;
-                    if (__builtin_expect(np > 1, 0)) {
-                        int W = (end - bal + 1 + 3) & ~3;  // (recomputed behind a barrier so that the plane addresses are not
-                        asm volatile("" : "+s"(W));       //  hoisted out of the row's step loop into scalar registers)
-                        *(uint32_t *)(drow + (uint64_t)W + c) = (uint32_t)(pmeta[0] & 255) | ((uint32_t)(pmeta[1] & 255) << 8) | ((uint32_t)(pmeta[2] & 255) << 16) | ((uint32_t)(pmeta[3] & 255) << 24);
-                        *(uint32_t *)(drow + 2ull * W + c) = (uint32_t)((pmeta[0] >> 8) & 255) | ((uint32_t)((pmeta[1] >> 8) & 255) << 8) | ((uint32_t)((pmeta[2] >> 8) & 255) << 16) | ((uint32_t)((pmeta[3] >> 8) & 255) << 24);
-                        *(uint32_t *)(drow + 3ull * W + c) = (uint32_t)((pmeta[0] >> 16) & 255) | ((uint32_t)((pmeta[1] >> 16) & 255) << 8) | ((uint32_t)((pmeta[2] >> 16) & 255) << 16) | ((uint32_t)((pmeta[3] >> 16) & 255) << 24);
+                    int Wl = (end_ - bal + 1 + 3) & ~3;  // (recomputed behind the barrier above so that the plane addresses are
+                                                        //  not hoisted out of the row's step loop into scalar registers)
+#pragma unroll
+                    for (int q = 0; q < QPT; q++) {
+                        if (j0 + 4 * q > end_) continue;  // beyond the row's storage
+                        const int4 wq = make_int4(wv4[4 * q], wv4[4 * q + 1], wv4[4 * q + 2], wv4[4 * q + 3]);
+                        const int cq = c + 4 * q;
+                        if (!wide) *(int4 *)(HG + ((j0 + 4 * q) & win_mask)) = wq;
+                        *(uint32_t *)(drow + cq) = (uint32_t)codev[4 * q] | ((uint32_t)codev[4 * q + 1] << 8) |
+                                                   ((uint32_t)codev[4 * q + 2] << 16) | ((uint32_t)codev[4 * q + 3] << 24);
+                        if (keep) *(int4 *)(Vrow + cq) = wq;
+                        if (__builtin_expect(np > 1, 0)) {
+                            const int *pm = pmeta + 4 * q;
+                            *(uint32_t *)(drow + (uint64_t)Wl + cq) = (uint32_t)(pm[0] & 255) | ((uint32_t)(pm[1] & 255) << 8) | ((uint32_t)(pm[2] & 255) << 16) | ((uint32_t)(pm[3] & 255) << 24);
+                            *(uint32_t *)(drow + 2ull * Wl + cq) = (uint32_t)((pm[0] >> 8) & 255) | ((uint32_t)((pm[1] >> 8) & 255) << 8) | ((uint32_t)((pm[2] >> 8) & 255) << 16) | ((uint32_t)((pm[3] >> 8) & 255) << 24);
+                            *(uint32_t *)(drow + 3ull * Wl + cq) = (uint32_t)((pm[0] >> 16) & 255) | ((uint32_t)((pm[1] >> 16) & 255) << 8) | ((uint32_t)((pm[2] >> 16) & 255) << 16) | ((uint32_t)((pm[3] >> 16) & 255) << 24);
+                        }
                     }
                 }
             }
@@ -1733,6 +1774,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             // workgroup size: a row of the widest band should take about two steps, and the launch should still fill
             // the GPU (blocks per CU: LDS and 28 waves)
             int nt = mq >= 3072 ? 512 : (mq >= 768 ? 256 : 128);
+            int cpt = 4;  // columns per lane and step of the packed kernel
             if (packed) {
                 // workgroup size: the one that keeps the most waves resident (LDS and the 28 wave slots of a CU bound the
                 // workgroups per CU; the problems still to be run -- this sub-batch and the ones that will overlap it --
@@ -1740,7 +1782,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 auto by_lds = [&](int t) { return std::max<size_t>(1, (160 * 1024) / (poa_pk_lds_bytes(hg_cols, lds_cols, t) + 256)); };
                 size_t best_waves = 0;
                 for (int t = 128; t <= 512; t += 64) {
-                    const size_t per_cu = std::min<size_t>(by_lds(t), (size_t)(28 / (t / 64)));
+                    const size_t per_cu = std::min<size_t>(by_lds(t), (size_t)((cpt == 8 ? 20 : 28) / (t / 64)));
                     const size_t waves = std::min<size_t>(n - i0 + in_flight_other, per_cu * (size_t)ctx->n_cu) * (size_t)(t / 64);
                     if (waves > best_waves) { best_waves = waves; nt = t; }
                 }
@@ -1788,15 +1830,15 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                                 wsel * 2, sum[0], sum[1], sum[6], sum[2], sum[3], sum[4], sum[5], tot);
                     }
                 } else {
+#define POA_PK_LAUNCH2(T, D, C)                                                                                             \
+    {                                                                                                                       \
+        chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<T, false, D, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_poa_dp_pk<T, false, D, C>), dim3(nb), dim3(T), lds, st, POA_PK_ARGS);                        \
+    }
 #define POA_PK_LAUNCH(T)                                                                                                    \
     case T:                                                                                                                 \
-        if (def_pen) {                                                                                                      \
-            chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<T, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL((k_poa_dp_pk<T, false, true>), dim3(nb), dim3(T), lds, st, POA_PK_ARGS);                    \
-        } else {                                                                                                            \
-            chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
-            hipLaunchKernelGGL((k_poa_dp_pk<T>), dim3(nb), dim3(T), lds, st, POA_PK_ARGS);                                 \
-        }                                                                                                                   \
+        if (def_pen) POA_PK_LAUNCH2(T, true, 4)                                                                             \
+        else POA_PK_LAUNCH2(T, false, 4)                                                                                    \
         break;
                     const bool def_pen = P.o1 == 4 && P.e1 == 2 && P.o2 == 24 && P.e2 == 1 && !(force && strstr(force, "generic"));
                     switch (nt) {
@@ -1804,6 +1846,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                         POA_PK_LAUNCH(384) POA_PK_LAUNCH(448) POA_PK_LAUNCH(512)
                     default: chk(hipErrorInvalidValue);
                     }
+#undef POA_PK_LAUNCH2
 #undef POA_PK_LAUNCH
                 }
             } else if (nt == 128) {
