@@ -39,6 +39,7 @@
 #define POA_ST_POOL 1
 #define POA_ST_NOALN 2
 #define POA_ST_TRACE 3
+#define POA_ST_RANGE 4  // 16-bit storage: a score came near the representable range, the problem is re-run in 32 bits
 
 struct poa_prob {
     uint64_t node0;  // first entry of the node table (entry 0 of a problem is the virtual source)
@@ -56,11 +57,13 @@ struct poa_prob {
     uint32_t pad;
 };
 
-struct poa_row {          // per DP row, 40 B
+struct poa_row {          // per DP row, 48 B
     int32_t beg, end;     // band
     uint64_t doff, voff;  // direction row / value row in the pool
     uint32_t pred, npred; // predecessor row or predecessor-list slice; npred != 0 only on the first row of a node
     int32_t lmax, rmax;   // leftmost / rightmost column of the row maximum
+    int32_t base, hmax;   // 16-bit storage (k_poa_dp_pk<.., H16>): the row's values are stored relative to `base`;
+                          // hmax = the row maximum (absolute).  0 / unused otherwise.
 };
 
 struct poa_out {          // per problem, 40 B
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
 __global__ __launch_bounds__(64) void k_poa_traceback(
     uint32_t n, const poa_prob *__restrict__ probs, const poa_row *__restrict__ rows,
     const uint32_t *__restrict__ preds, const uint8_t *__restrict__ pool, poa_out *__restrict__ outs,
-    uint8_t *__restrict__ ops, uint32_t *__restrict__ orow)
+    uint8_t *__restrict__ ops, uint32_t *__restrict__ orow, int code_xor)
 {
     const uint32_t pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= n) return;
@@ -615,11 +618,11 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
         const uint64_t doff = rw.doff;
         if (j < beg || j > end) { bad = true; break; }
         const uint64_t c = (uint64_t)(j - bal);
-        const int code = pool[doff + c];
-        // direction byte: [1:0] source of Ht (M, E1, E2), [3:2] E1/E2 opened here, [5:4] F chosen for H (0 none, 1 F1,
-        // 2 F2), [7:6] F1/F2 opened here
+        const int code = pool[doff + c] ^ code_xor;  // the 16-bit DP kernel stores the F-open bits inverted
+        // direction byte: [1:0] source of Ht (M, E1, E2), [3:2] E1/E2 opened here, [4] F1 > Ht, [5] F2 > max(Ht, F1),
+        // [7:6] F1/F2 opened here
         const int hts = code & 3;
-        const int fsel = (code >> 4) & 3;
+        const int fsel = (code & 32) ? 2 : ((code >> 4) & 1);  // bit 5: F2 beat everything; bit 4: F1 beat Ht (both may be set)
         const int hs = fsel ? 2 + fsel : hts;
         const int src = st == 0 ? hs : (st == 5 ? hts : st);
         if (nops + 1 >= cap) { bad = true; break; }
@@ -665,11 +668,70 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
 //   * node-end value rows in HBM are the same packed words (4 B per cell);
 //   * single-predecessor rows whose predecessor is not the row above ("far") use the lean path as well, with
 //     their five words coming from HBM instead of LDS.
+// ---- packed 16-bit helpers (two cells per 32-bit register; v_pk_* instructions)
+typedef short pk16 __attribute__((ext_vector_type(2)));
+typedef unsigned short pku16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk16 pk(int x) { return __builtin_bit_cast(pk16, x); }
+__device__ __forceinline__ pku16 pku(int x) { return __builtin_bit_cast(pku16, x); }
+__device__ __forceinline__ int ipk(pk16 x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ int ipk(pku16 x) { return __builtin_bit_cast(int, x); }
+__device__ __forceinline__ int pk_bcast(int v) { return (int)(((uint32_t)v & 0xffffu) | ((uint32_t)v << 16)); }
+__device__ __forceinline__ int pk_make(int lo, int hi) { return (int)(((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16)); }
+__device__ __forceinline__ int pk_adds(int a, int b) { return ipk(__builtin_elementwise_add_sat(pk(a), pk(b))); }  // saturating
+__device__ __forceinline__ int pk_subs(int a, int b) { return ipk(__builtin_elementwise_sub_sat(pk(a), pk(b))); }
+__device__ __forceinline__ int pk_add(int a, int b) { return ipk(pku(a) + pku(b)); }                               // wrapping
+__device__ __forceinline__ int pk_sub(int a, int b) { return ipk(pku(a) - pku(b)); }
+__device__ __forceinline__ int pk_max(int a, int b) { return ipk(__builtin_elementwise_max(pk(a), pk(b))); }
+__device__ __forceinline__ int pk_min(int a, int b) { return ipk(__builtin_elementwise_min(pk(a), pk(b))); }
+__device__ __forceinline__ int pk_minu(int a, int b) { return ipk(__builtin_elementwise_min(pku(a), pku(b))); }
+__device__ __forceinline__ int pk_mad(int a, int b, int c) { return ipk(pku(a) * pku(b) + pku(c)); }
+// Written as instructions: left to itself the compiler recognises min(x, 1) / small shifts of packed values as per-half
+// compares and 16-bit scalar operations and un-packs them (v_cmp_ne_u16 + v_cndmask + v_perm per half).
+template <int C>
+__device__ __forceinline__ int pk_minu_c(int a)  // per half: min(a, C) unsigned, C an inline constant
+{
+    int r;
+    asm("v_pk_min_u16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "n"(C));
+    return r;
+}
+template <int C>
+__device__ __forceinline__ int pk_shr_c(int a)  // per half: a >> C, logical
+{
+    int r;
+    asm("v_pk_lshrrev_b16 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "n"(C), "v"(a));
+    return r;
+}
+template <int C>
+__device__ __forceinline__ int pk_addu_c(int a)  // per half: a + C, wrapping
+{
+    int r;
+    asm("v_pk_add_u16 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "n"(C));
+    return r;
+}
+__device__ __forceinline__ int pk_mad_v(int a, int b, int c)  // per half: a * b + c, wrapping
+{
+    int r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <int C>
+__device__ __forceinline__ int pk_mad_c(int a, int c)  // per half: a * C + c, C an inline constant
+{
+    int r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "n"(C), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int pk_lo(int a) { return (int)(short)(a & 0xffff); }  // sign-extended halves
+__device__ __forceinline__ int pk_hi(int a) { return a >> 16; }
+
 // DEF: the gap penalties are abPOA's defaults (4/2, 24/1 => 3 + 5 bit deltas), known at compile time.
 // CPT: columns per lane and step (4 or 8).  Eight halve the per-lane-step overhead (wave scan, cross-wave exchange, address
 // arithmetic) per cell but need ~22 more vector registers (five waves per SIMD instead of seven); measured on config 3 the
 // instruction count per cell does not drop and the step is 3 % slower, so only CPT = 4 is instantiated.
-template <int NT, bool STAMP = false, bool DEF = false, int CPT = 4>
+// H16: the row state (LDS window and HBM value rows) is an int16 plane of H relative to a per-row base (the
+// predecessors' maximum) plus a byte plane of the gap deltas: 3 B per column.  Scores that come within 2 768 of the int16
+// range stop the problem with POA_ST_RANGE and the host re-runs it with 32-bit words.
+template <int NT, bool STAMP = false, bool DEF = false, int CPT = 4, bool H16 = false>
 __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
     const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
     const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
@@ -687,12 +749,71 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
     int4 *sX = (int4 *)smem;                  // [2][NW] {scan1, scan2, last1, last2} per wave
     int4 *sRed = sX + 2 * NW;                 // [NW] {row max, -leftmost, rightmost, 0} per wave
     int32_t *edgeW = (int32_t *)(sRed + NW);  // [2] (+2 pad)
-    int4 *sRow = (int4 *)(edgeW + 4);         // [3] the row's parameters, written by wave 0 (see the row loop)
-    int4 *sLead = sRow + 3;                   // [4] wave 0's allocator state and counters
-    constexpr int HDR = (3 * NW + 1 + 3 + 4) * 16;
-    int32_t *HG = (int32_t *)(smem + HDR);                       // [hg_cols] (H << 8) | g
-    uint16_t *Qn = (uint16_t *)(smem + HDR + 4ull * hg_cols);    // [lds_cols / 4] four column codes per halfword
+    int4 *sRow = (int4 *)(edgeW + 4);         // [4] the row's parameters, written by wave 0 (see the row loop)
+    int4 *sLead = sRow + 4;                   // [4] wave 0's allocator state and counters
+    constexpr int HDR = (3 * NW + 1 + 4 + 4) * 16;
+    int32_t *HG = (int32_t *)(smem + HDR);                       // [hg_cols] (H << 8) | g            (32-bit storage)
+    int16_t *H16a = (int16_t *)(smem + HDR);                     // [hg_cols] H - row base            (16-bit storage)
+    uint8_t *G8a = smem + HDR + 2ull * hg_cols;                  // [hg_cols] g
+    uint16_t *Qn = (uint16_t *)(smem + HDR + (H16 ? 3ull : 4ull) * hg_cols);  // [lds_cols / 4] four column codes per halfword
     const int edge_idx = (int)(edgeW - HG);  // edgeW addressed through HG, see phase 1
+    constexpr int VB = H16 ? 3 : 4;  // bytes per cell of a value row in HBM
+    // ---- accessors of the row state.  A "word" is (H << 8) | g whatever the storage; with 16-bit storage H is relative to
+    // the base of the row the word belongs to (the consumer adds base differences).
+    auto mk = [](int h, uint32_t g) -> int { return (int)(((uint32_t)h << 8) | (g & 255u)); };
+    auto lds_quad = [&](int j) -> int4 {
+        if constexpr (!H16) return *(const int4 *)(HG + (j & win_mask));
+        else {
+            const uint2 hh = *(const uint2 *)(H16a + (j & win_mask));
+            const uint32_t gg = *(const uint32_t *)(G8a + (j & win_mask));
+            return make_int4(mk((int)(hh.x << 16) >> 16, gg), mk((int)hh.x >> 16, gg >> 8), mk((int)(hh.y << 16) >> 16, gg >> 16),
+                             mk((int)hh.y >> 16, gg >> 24));
+        }
+    };
+    // column j of the row above, or the word the previous step parked in edgeW (edge != 0)
+    auto lds_word = [&](int j, bool edge, int ebuf) -> int {
+        if constexpr (!H16) {
+            // one LDS read through an index (a pointer select would turn into a flat load, which also waits for the
+            // outstanding global stores)
+            int w = HG[edge ? edge_idx + ebuf : (j & win_mask)];
+            asm volatile("" : "+v"(w));
+            return w;
+        } else {
+            const int we = edgeW[ebuf];
+            const int wl = mk((int)H16a[j & win_mask], (uint32_t)G8a[j & win_mask]);
+            return edge ? we : wl;
+        }
+    };
+    auto lds_store = [&](int j, int4 w) {
+        if constexpr (!H16) *(int4 *)(HG + (j & win_mask)) = w;
+        else {
+            auto c16 = [](int wv) -> uint32_t { int h = wv >> 8; h = h < -32768 ? -32768 : h; return (uint32_t)h & 0xffffu; };
+            *(uint2 *)(H16a + (j & win_mask)) = make_uint2(c16(w.x) | (c16(w.y) << 16), c16(w.z) | (c16(w.w) << 16));
+            *(uint32_t *)(G8a + (j & win_mask)) = ((uint32_t)w.x & 255u) | (((uint32_t)w.y & 255u) << 8) | (((uint32_t)w.z & 255u) << 16) | ((uint32_t)w.w << 24);
+        }
+    };
+    // value rows in HBM: `rowp` points at the row, Wr is its storage width, idx the column offset inside it
+    auto hbm_quad = [&](const uint8_t *rowp, int Wr, int idx) -> int4 {
+        if constexpr (!H16) return *(const int4 *)((const int32_t *)rowp + idx);
+        else {
+            const uint2 hh = *(const uint2 *)((const int16_t *)rowp + idx);
+            const uint32_t gg = *(const uint32_t *)(rowp + 2 * (int64_t)Wr + idx);
+            return make_int4(mk((int)(hh.x << 16) >> 16, gg), mk((int)hh.x >> 16, gg >> 8), mk((int)(hh.y << 16) >> 16, gg >> 16),
+                             mk((int)hh.y >> 16, gg >> 24));
+        }
+    };
+    auto hbm_word = [&](const uint8_t *rowp, int Wr, int idx) -> int {
+        if constexpr (!H16) return ((const int32_t *)rowp)[idx];
+        else return mk((int)((const int16_t *)rowp)[idx], (uint32_t)rowp[2 * (int64_t)Wr + idx]);
+    };
+    auto hbm_store = [&](uint8_t *rowp, int Wr, int idx, int4 w) {
+        if constexpr (!H16) *(int4 *)((int32_t *)rowp + idx) = w;
+        else {
+            auto c16 = [](int wv) -> uint32_t { int h = wv >> 8; h = h < -32768 ? -32768 : h; return (uint32_t)h & 0xffffu; };
+            *(uint2 *)((int16_t *)rowp + idx) = make_uint2(c16(w.x) | (c16(w.y) << 16), c16(w.z) | (c16(w.w) << 16));
+            *(uint32_t *)(rowp + 2 * (int64_t)Wr + idx) = ((uint32_t)w.x & 255u) | (((uint32_t)w.y & 255u) << 8) | (((uint32_t)w.z & 255u) << 16) | ((uint32_t)w.w << 24);
+        }
+    };
 
     const poa_prob pb = probs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -782,13 +903,15 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
     if (leader) {
         lead_t L = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         // two scratch value rows for rows wider than the LDS window (they only feed the row directly below)
-        if (win_mask != 0xFFFFFFFFu) L.wide_scratch = alloc(L, L.vcur, L.vendp, 8ull * lds_cols);
+        if (win_mask != 0xFFFFFFFFu) L.wide_scratch = alloc(L, L.vcur, L.vendp, 2ull * VB * lds_cols);
         lead_store(L);
     }
     int prev_beg = 0, prev_end = -1, prev_lmax = 0, prev_rmax = 0;
+    int prev_base = 0, prev_hmax = 0;  // (16-bit storage) base and absolute maximum of the row just computed
+    int danger = 0;                    // (16-bit storage) this lane saw a score near the int16 range
     bool prev_lds = true;  // the row just computed is resident in the LDS window (false after a row wider than the window)
     uint32_t seq_word = 0, seq_word_idx = 0xFFFFFFFFu;
-    bool stop = false;
+    bool stop = false, range_stop = false;
 
     for (uint32_t v = 0; v < pb.n_nodes && !stop; v++) {
     const uint4 nt = ntab[v];
@@ -857,10 +980,35 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
             if (last || wide) L.vcells += (uint64_t)(end - beg + 1);
             const uint64_t doff = alloc(L, L.dcur, L.dend, (uint64_t)W * (np > 1 ? 4u : 1u));
             uint64_t voff = 0;
-            if (last && !L.failed) voff = alloc(L, L.vcur, L.vendp, 4ull * (uint64_t)W);
-            else if (wide) voff = L.wide_scratch + (r & 1u) * 4ull * lds_cols;
+            if (last && !L.failed) voff = alloc(L, L.vcur, L.vendp, (uint64_t)VB * (uint64_t)W);
+            else if (wide) voff = L.wide_scratch + (r & 1u) * (uint64_t)VB * lds_cols;
             int pbeg = prev_beg, pend = prev_end;
             uint64_t vpo = 0;
+            // (16-bit storage) this row's base = the largest maximum among its predecessors; dlt = what to add to the
+            // single predecessor's stored values to bring them into this row's frame
+            int base = 0, dlt = 0;
+            if constexpr (H16) {
+                if (r > 0) {
+                    if (!first) { base = prev_hmax; dlt = prev_base - base; }
+                    else {
+                        base = INT32_MIN;
+                        const uint32_t *pl2 = plist;
+                        int pb1 = 0;
+                        for (int t = 0; t < np; t++) {
+                            const uint32_t p = np == 1 ? ps : pl2[ps + t];
+                            int hm, bs;
+                            if (p == r - 1) { hm = prev_hmax; bs = prev_base; }
+                            else {
+                                hm = __builtin_amdgcn_readfirstlane(R[p].hmax);
+                                bs = __builtin_amdgcn_readfirstlane(R[p].base);
+                            }
+                            base = hm > base ? hm : base;
+                            pb1 = bs;
+                        }
+                        dlt = pb1 - base;  // meaningful for np == 1 only
+                    }
+                }
+            }
             if (single && !sp_near) {
                 // uniform values of a far row: read them into scalar registers right here, so that their s_waitcnt vmcnt
                 // stays inside this branch
@@ -876,10 +1024,12 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                     R[r].beg = beg; R[r].end = end;
                     R[r].doff = doff; R[r].voff = voff;
                     R[r].pred = ps; R[r].npred = first ? (uint32_t)np : 0u;
+                    R[r].base = base;
                 }
                 sRow[0] = make_int4(beg, end, (int)(uint32_t)doff, (int)(uint32_t)(doff >> 32));
                 sRow[1] = make_int4((int)(uint32_t)voff, (int)(uint32_t)(voff >> 32), pbeg, pend);
                 sRow[2] = make_int4((int)(uint32_t)vpo, (int)(uint32_t)(vpo >> 32), L.failed, 0);
+                sRow[3] = make_int4(base, dlt, 0, 0);
             }
         }
         POA_LDS_BARRIER();
@@ -892,25 +1042,32 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
         const int pbeg = __builtin_amdgcn_readfirstlane(rw1.z), pend = __builtin_amdgcn_readfirstlane(rw1.w);
         const uint64_t vpo = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(rw2.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(rw2.x);
         if (__builtin_amdgcn_readfirstlane(rw2.z)) { stop = true; break; }
+        int base = 0, dlt8 = 0;  // (16-bit storage) row base; single-predecessor frame shift, in word units (<< 8)
+        if constexpr (H16) {
+            const int4 rw3 = sRow[3];
+            base = __builtin_amdgcn_readfirstlane(rw3.x);
+            dlt8 = __builtin_amdgcn_readfirstlane(rw3.y) * 256;
+        }
         const int bal = beg & ~3;
         const int W = (end - bal + 1 + 3) & ~3;  // storage width / plane stride
         // A row wider than the LDS window (columns would alias) is not written to LDS: it keeps a value row in HBM like
         // a node-end row does (in one of two scratch rows unless it ends a node), and the row below reads it from there.
         const bool wide = (uint32_t)W + 8u > hg_cols;
         const bool keep = last || wide;
-        int32_t *Vrow = (int32_t *)(pool + voff);  // value row: packed words
+        uint8_t *Vrow = pool + voff;  // value row
         uint8_t *drow = pool + doff;
         const int gcode = gb == 'A' ? 0 : (gb == 'C' ? 1 : (gb == 'G' ? 2 : (gb == 'T' ? 3 : 4)));
         const int sc_eq = gcode == 4 ? 0 : P.match, sc_ne = gcode == 4 ? 0 : -P.mismatch;
         const int gsh = gcode & 3;            // bit of the one-hot column code that means "equal to this row's base"
         const int sc_mm = sc_eq - sc_ne;
-        const int32_t *Vp = (const int32_t *)(pool + vpo);
+        const uint8_t *Vp = pool + vpo;  // value row of a far single predecessor
         const int balp = pbeg & ~3;
         stamp(0);
 
         POA_MARK("row_steps");
         int carry1 = POA_IDENT, carry2 = POA_IDENT, left1 = POA_IDENT, left2 = POA_IDENT;
         int best = INT32_MIN, lpos = beg, rpos = beg;
+        int zacc = -1;  // (16-bit storage) per half: min over the row's active cells of (H + 32000) as u16
         int buf = 0;
         for (int c0 = 0; c0 < W; c0 += STEP, buf ^= 1) {
             const int c = c0 + CPT * tid;
@@ -923,6 +1080,9 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
             int agg1 = POA_IDENT, agg2 = POA_IDENT, alast1 = POA_IDENT, alast2 = POA_IDENT;
 #pragma unroll
             for (int k = 0; k < CPT; k++) { ht[k] = POA_NEG; meta[k] = (o1 << 8) | (o2 << 16); pmeta[k] = 0; }
+            // (16-bit storage) the same, two cells per register: Ht, flags (hts | of1 << 2 | of2 << 3), u1, u2
+            int hq[2] = {(int)0x80008000, (int)0x80008000}, fq[2] = {0, 0};
+            int u1q[2] = {0x00040004, 0x00040004}, u2q[2] = {0x00180018, 0x00180018};
             uint32_t qn = 0u;  // one-hot code nibbles of this lane's columns
             if (wave_act) {
 #pragma unroll
@@ -945,22 +1105,112 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
             if constexpr (STAMP) tacc[7] += (wave_act ? (1ull << 42) : 0ull) + (fastw ? 1ull : 0ull) + ((fastw && (lp || rp)) ? (1ull << 21) : 0ull);
         POA_MARK("p1_fast");
             if (__builtin_expect(fastw, 1)) {
+              if constexpr (H16) {
+                // ---------------- interior path, phase 1, two cells per instruction
+                static_assert(!H16 || (CPT == 4 && DEF), "the packed 16-bit path is written for 4 columns per lane and the default penalties");
+                int hp[2];      // the predecessor's H pairs (cells 0,1 / 2,3), in ITS frame
+                uint32_t gg;    // its four g bytes
+                int hprev;      // its H at column j0 - 1
+                if (__builtin_expect(sp_near, 1)) {
+                    const uint2 hh = *(const uint2 *)(H16a + (j0 & win_mask));
+                    gg = *(const uint32_t *)(G8a + (j0 & win_mask));
+                    hp[0] = (int)hh.x; hp[1] = (int)hh.y;
+                    if (tid == NT - 1) edgeW[buf] = ((int)hh.y >> 16) << 8;
+                    const int he = edgeW[buf ^ 1] >> 8;
+                    const int hl = (int)H16a[(j0 > 0 ? j0 - 1 : 0) & win_mask];
+                    hprev = (tid == 0 && c0 > 0) ? he : hl;
+                } else {
+                    const int Wp = (pend - balp + 1 + 3) & ~3;
+                    const int idx = j0 - balp;
+                    const uint2 hh = *(const uint2 *)((const int16_t *)Vp + idx);
+                    gg = *(const uint32_t *)(Vp + 2 * (int64_t)Wp + idx);
+                    hprev = (int)((const int16_t *)Vp)[idx > 0 ? idx - 1 : 0];
+                    hp[0] = (int)hh.x; hp[1] = (int)hh.y;
+                    // consume the loads inside this branch (see the 32-bit path)
+                    asm volatile("" : "+v"(hp[0]), "+v"(hp[1]), "+v"(gg), "+v"(hprev));
+                }
+                auto phase1h = [&](auto edge_c) {
+                    constexpr bool EDGE = decltype(edge_c)::value;
+                    constexpr int SENT = (int)0x80008000;
+                    int gp[2] = {(int)__builtin_amdgcn_perm(0u, gg, 0x0c010c00u), (int)__builtin_amdgcn_perm(0u, gg, 0x0c030c02u)};
+                    if constexpr (EDGE) {
+                        if (rp) {  // columns right of pend: H = sentinel, g = 0
+                            int d = j0 - pend - 1;
+                            d = d < -64 ? -64 : (d > 64 ? 64 : d);
+                            const int db = pk_bcast(d);
+                            const int in0 = ipk(pk(pk_add(db, 0x00010000)) >> 15), in1 = ipk(pk(pk_add(db, 0x00030002)) >> 15);  // 0xffff = inside
+                            hp[0] = (hp[0] & in0) | (SENT & ~in0); hp[1] = (hp[1] & in1) | (SENT & ~in1);
+                            gp[0] &= in0; gp[1] &= in1;
+                        }
+                    }
+                    const int dltp = pk_bcast(dlt8 >> 8), ned = pk_bcast(sc_ne + (dlt8 >> 8)), mmp = pk_bcast(sc_mm);
+                    // M: the predecessor's columns j-1, plus match / mismatch (and the frame shift)
+                    const int sp0 = (int)__builtin_amdgcn_perm((uint32_t)hp[0], (uint32_t)hprev, 0x05040100u);  // (h[-1], h0)
+                    const int sp1 = (int)__builtin_amdgcn_perm((uint32_t)hp[1], (uint32_t)hp[0], 0x05040302u);  // (h1, h2)
+                    const int xb = pk_bcast((int)(qn >> gsh));  // bit 4k of either half: cell k matches
+                    const int eq0 = ipk(pku(xb) >> pku(0x00040000)) & 0x00010001, eq1 = ipk(pku(xb) >> pku(0x000c0008)) & 0x00010001;
+                    const int m0 = pk_adds(sp0, pk_mad(eq0, mmp, ned)), m1 = pk_adds(sp1, pk_mad(eq1, mmp, ned));
+                    const int hd[2] = {pk_adds(hp[0], dltp), pk_adds(hp[1], dltp)};
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int g1 = gp[q] & 0x00070007, g2 = pk_shr_c<3>(gp[q]);
+                        const int ev1 = pk_subs(hd[q], g1), ev2 = pk_subs(hd[q], g2);
+                        const int m = q ? m1 : m0;
+                        const int h = pk_max(pk_max(m, ev1), ev2);
+                        const int u1r = pk_subs(h, ev1);
+                        const int t = pk_minu_c<1>(pk_subs(h, m)), e = pk_minu_c<1>(u1r);
+                        const int hts = pk_mad_v(t, e, t);  // 0 = M, 1 = E1, 2 = E2 (first maximum wins)
+                        u1q[q] = pk_min(u1r, 0x00040004);
+                        u2q[q] = pk_min(pk_subs(h, ev2), 0x00180018);
+                        const int of1 = pk_shr_c<3>(pk_addu_c<2>(g1)), of2 = pk_shr_c<5>(pk_addu_c<7>(g2));
+                        fq[q] = pk_mad_c<8>(of2, pk_mad_c<4>(of1, hts));
+                        hq[q] = h;
+                    }
+                    if constexpr (EDGE) {
+                        if (lp) {  // lane 0's cells left of beg stay out of the scan
+                            int d = j0 - beg;
+                            d = d < -64 ? -64 : (d > 64 ? 64 : d);
+                            const int db = pk_bcast(d);
+                            const int out0 = ipk(pk(pk_add(db, 0x00010000)) >> 15), out1 = ipk(pk(pk_add(db, 0x00030002)) >> 15);  // 0xffff = left of beg
+                            hq[0] = (SENT & out0) | (hq[0] & ~out0); hq[1] = (SENT & out1) | (hq[1] & ~out1);
+                        }
+                    }
+                    // lane-relative a_k = Ht_k + e k  (16 bit), the lane's maximum and last value (32 bit, row-relative)
+                    const int r1a = pk_add(hq[0], 0x00020000), r1b = pk_add(hq[1], 0x00060004);
+                    const int r2a = pk_add(hq[0], 0x00010000), r2b = pk_add(hq[1], 0x00030002);
+                    const int x1 = pk_max(r1a, r1b), x2 = pk_max(r2a, r2b);
+                    const int ag1 = pk_lo(x1) > pk_hi(x1) ? pk_lo(x1) : pk_hi(x1);
+                    const int ag2 = pk_lo(x2) > pk_hi(x2) ? pk_lo(x2) : pk_hi(x2);
+                    agg1 = ag1 + base1; agg2 = ag2 + base2;
+                    alast1 = pk_hi(r1b) + base1; alast2 = pk_hi(r2b) + base2;
+                };
+                if (__builtin_expect(lp || rp, 0)) phase1h(std::true_type{});
+                else phase1h(std::false_type{});
+              } else {
                 // ---------------- interior path, phase 1
                 int4 hv[QPT];
                 int hprev;
                 if (__builtin_expect(sp_near, 1)) {
 #pragma unroll
-                    for (int q = 0; q < QPT; q++) hv[q] = *(const int4 *)(HG + ((j0 + 4 * q) & win_mask));
+                    for (int q = 0; q < QPT; q++) hv[q] = lds_quad(j0 + 4 * q);
                     if (tid == NT - 1) edgeW[buf] = hv[QPT - 1].w;
-                    // one LDS read through an index (a pointer select would turn into a flat load, which also waits
-                    // for the outstanding global stores)
-                    hprev = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : ((j0 > 0 ? j0 - 1 : 0) & win_mask)];
-                    asm volatile("" : "+v"(hprev));
+                    hprev = lds_word(j0 > 0 ? j0 - 1 : 0, tid == 0 && c0 > 0, buf ^ 1);
+                    if constexpr (H16) {
+#pragma unroll
+                        for (int q = 0; q < QPT; q++) { hv[q].x += dlt8; hv[q].y += dlt8; hv[q].z += dlt8; hv[q].w += dlt8; }
+                        hprev += dlt8;
+                    }
                     hprev >>= 8;
                 } else {
+                    const int Wp = (pend - balp + 1 + 3) & ~3;
 #pragma unroll
-                    for (int q = 0; q < QPT; q++) hv[q] = *(const int4 *)(Vp + (j0 - balp) + 4 * q);
-                    hprev = Vp[j0 - balp > 0 ? j0 - balp - 1 : 0];
+                    for (int q = 0; q < QPT; q++) hv[q] = hbm_quad(Vp, Wp, (j0 - balp) + 4 * q);
+                    hprev = hbm_word(Vp, Wp, j0 - balp > 0 ? j0 - balp - 1 : 0);
+                    if constexpr (H16) {
+#pragma unroll
+                        for (int q = 0; q < QPT; q++) { hv[q].x += dlt8; hv[q].y += dlt8; hv[q].z += dlt8; hv[q].w += dlt8; }
+                        hprev += dlt8;
+                    }
                     // consume the loads inside this branch: otherwise their s_waitcnt vmcnt lands in the code shared
                     // with near rows, where it would also wait for every outstanding direction / value store
 #pragma unroll
@@ -1017,6 +1267,7 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                 };
                 if (__builtin_expect(lp || rp, 0)) phase1(std::true_type{});
                 else phase1(std::false_type{});
+              }
         POA_MARK("p1_lean");
             } else if (wave_act && single) {
                 // ---------------- lean path, phase 1
@@ -1032,27 +1283,30 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                 if (sp_near) {
 #pragma unroll
                     for (int q = 0; q < QPT; q++) {
-                        const int4 hv = *(const int4 *)(HG + ((j0 + 4 * q) & win_mask));
+                        const int4 hv = lds_quad(j0 + 4 * q);
                         wj[4 * q] = hv.x; wj[4 * q + 1] = hv.y; wj[4 * q + 2] = hv.z; wj[4 * q + 3] = hv.w;
                     }
                     if (tid == NT - 1) edgeW[buf] = wj[CPT - 1];
-                    const int jm1 = j0 > 0 ? j0 - 1 : 0;
-                    wm0 = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : (jm1 & win_mask)];
-                    asm volatile("" : "+v"(wm0));
+                    wm0 = lds_word(j0 > 0 ? j0 - 1 : 0, tid == 0 && c0 > 0, buf ^ 1);
                 } else {
                     const int idx = j0 - balp;
                     const int Wp = (pend - balp + 1 + 3) & ~3;
 #pragma unroll
                     for (int q = 0; q < QPT; q++) {
                         int4 hv = make_int4(0, 0, 0, 0);
-                        if (idx + 4 * q >= 0 && idx + 4 * q < Wp) hv = *(const int4 *)(Vp + idx + 4 * q);
+                        if (idx + 4 * q >= 0 && idx + 4 * q < Wp) hv = hbm_quad(Vp, Wp, idx + 4 * q);
                         wj[4 * q] = hv.x; wj[4 * q + 1] = hv.y; wj[4 * q + 2] = hv.z; wj[4 * q + 3] = hv.w;
                     }
-                    wm0 = (idx >= 1 && idx - 1 < Wp) ? Vp[idx - 1] : 0;
+                    wm0 = (idx >= 1 && idx - 1 < Wp) ? hbm_word(Vp, Wp, idx - 1) : 0;
                     // wait here, not in shared code
 #pragma unroll
                     for (int k = 0; k < CPT; k++) asm volatile("" : "+v"(wj[k]));
                     asm volatile("" : "+v"(wm0));
+                }
+                if constexpr (H16) {
+#pragma unroll
+                    for (int k = 0; k < CPT; k++) wj[k] += dlt8;
+                    wm0 += dlt8;
                 }
                 bool inprev = j0 >= 1 && (unsigned)(j0 - 1 - pbeg) <= pspan;
 #pragma unroll
@@ -1101,38 +1355,44 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                         const uint32_t p = plist[ps + t];
                         int wj[CPT], wm0 = 0;
                         int bp, ep;
+                        int pd8 = 0;  // (16-bit storage) frame shift of this predecessor, in word units
                         if (p == r - 1 && prev_lds) {
                             bp = prev_beg; ep = prev_end;
+                            if constexpr (H16) pd8 = (prev_base - base) * 256;
 #pragma unroll
                             for (int q = 0; q < QPT; q++) {
-                                const int4 hv = *(const int4 *)(HG + ((j0 + 4 * q) & win_mask));
+                                const int4 hv = lds_quad(j0 + 4 * q);
                                 wj[4 * q] = hv.x; wj[4 * q + 1] = hv.y; wj[4 * q + 2] = hv.z; wj[4 * q + 3] = hv.w;
                             }
                             if (tid == NT - 1) edgeW[buf] = wj[CPT - 1];
-                            const int jm1 = j0 > 0 ? j0 - 1 : 0;
-                            wm0 = HG[(tid == 0 && c0 > 0) ? edge_idx + (buf ^ 1) : (jm1 & win_mask)];
-                            asm volatile("" : "+v"(wm0));
+                            wm0 = lds_word(j0 > 0 ? j0 - 1 : 0, tid == 0 && c0 > 0, buf ^ 1);
                         } else {
                             bp = __builtin_amdgcn_readfirstlane(R[p].beg);
                             ep = __builtin_amdgcn_readfirstlane(R[p].end);
                             const uint64_t vo = R[p].voff;
                             const uint64_t vos = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(vo >> 32)) << 32) |
                                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vo);
-                            const int32_t *Vq = (const int32_t *)(pool + vos);
+                            const uint8_t *Vq = pool + vos;
+                            if constexpr (H16) pd8 = (__builtin_amdgcn_readfirstlane(R[p].base) - base) * 256;
                             const int balq = bp & ~3;
                             const int Wq = (ep - balq + 1 + 3) & ~3;
                             const int idx = j0 - balq;
 #pragma unroll
                             for (int q = 0; q < QPT; q++) {
                                 int4 hv = make_int4(0, 0, 0, 0);
-                                if (idx + 4 * q >= 0 && idx + 4 * q < Wq) hv = *(const int4 *)(Vq + idx + 4 * q);
+                                if (idx + 4 * q >= 0 && idx + 4 * q < Wq) hv = hbm_quad(Vq, Wq, idx + 4 * q);
                                 wj[4 * q] = hv.x; wj[4 * q + 1] = hv.y; wj[4 * q + 2] = hv.z; wj[4 * q + 3] = hv.w;
                             }
-                            wm0 = (idx >= 1 && idx - 1 < Wq) ? Vq[idx - 1] : 0;
+                            wm0 = (idx >= 1 && idx - 1 < Wq) ? hbm_word(Vq, Wq, idx - 1) : 0;
                             // wait here, not in shared code
 #pragma unroll
                             for (int k = 0; k < CPT; k++) asm volatile("" : "+v"(wj[k]));
                             asm volatile("" : "+v"(wm0));
+                        }
+                        if constexpr (H16) {
+#pragma unroll
+                            for (int k = 0; k < CPT; k++) wj[k] += pd8;
+                            wm0 += pd8;
                         }
                         const unsigned pspan = (unsigned)(ep - bp);
 #pragma unroll
@@ -1175,6 +1435,20 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                     agg1 = a1 > agg1 ? a1 : agg1;
                     agg2 = a2 > agg2 ? a2 : agg2;
                     if (k == CPT - 1) { alast1 = a1; alast2 = a2; }
+                }
+            }
+            if constexpr (H16) {
+                // the cold paths worked on 32-bit cells: hand their result over in the packed form, so that only that is
+                // alive across the barrier
+                if (!fastw && wave_act) {
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        auto c16 = [](int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); };
+                        hq[q] = pk_make(c16(ht[2 * q]), c16(ht[2 * q + 1]));
+                        fq[q] = pk_make(meta[2 * q] & 15, meta[2 * q + 1] & 15);
+                        u1q[q] = pk_make((meta[2 * q] >> 8) & 255, (meta[2 * q + 1] >> 8) & 255);
+                        u2q[q] = pk_make((meta[2 * q] >> 16) & 255, (meta[2 * q + 1] >> 16) & 255);
+                    }
                 }
             }
         POA_MARK("scan");
@@ -1222,6 +1496,89 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                 int run2 = pre2 > x2 ? pre2 : x2;
         POA_MARK("p2_fast");
                 if (__builtin_expect(fastw, 1)) {
+                  if constexpr (H16) {
+                    // ---------------- interior path, phase 2, two cells per instruction
+                    auto phase2h = [&](auto edge_c) {
+                        constexpr bool EDGE = decltype(edge_c)::value;
+                        constexpr int SENT = (int)0x80008000;
+                        auto c16 = [](int x) { return x < -32768 ? -32768 : (x > 32767 ? 32767 : x); };
+                        // lane-relative a_k again (cheaper to redo than to keep), and the in-lane part of the max-plus scan:
+                        // R_k = max(Rin, a_0 .. a_{k-1}) for the four cells, as two pairs
+                        int f[2][2], t[2][2];  // [gap][pair]: F candidates; 0 where F would be opened from the previous column
+#pragma unroll
+                        for (int g = 0; g < 2; g++) {
+                            const int A0 = pk_add(hq[0], g ? 0x00010000 : 0x00020000), A1 = pk_add(hq[1], g ? 0x00030002 : 0x00060004);
+                            const int Rin = c16((g ? run2 : run1) - (g ? base2 : base1)), Lin = c16((g ? la2 : la1) - (g ? base2 : base1));
+                            const int R01 = pk_max(pk_bcast(Rin), (int)(((uint32_t)A0 << 16) | 0x8000u));           // (Rin, max(Rin, a0))
+                            const int M01 = pk_max(R01, A0);                                                      // (.., max(Rin, a0, a1))
+                            const int X2 = (int)__builtin_amdgcn_perm((uint32_t)M01, (uint32_t)M01, 0x07060706u);  // both = max(Rin, a0, a1)
+                            const int R23 = pk_max(X2, (int)(((uint32_t)A1 << 16) | 0x8000u));                      // (X, max(X, a2))
+                            f[g][0] = pk_subs(R01, g ? 0x00190018 : 0x00060004);  // - (o + e k)
+                            f[g][1] = pk_subs(R23, g ? 0x001b001a : 0x000a0008);
+                            const int L01 = (int)__builtin_amdgcn_perm((uint32_t)A0, (uint32_t)Lin, 0x05040100u);  // (Lin, a0)
+                            const int L23 = (int)__builtin_amdgcn_perm((uint32_t)A1, (uint32_t)A0, 0x05040302u);   // (a1, a2)
+                            t[g][0] = pk_minu_c<1>(pk_sub(R01, L01));
+                            t[g][1] = pk_minu_c<1>(pk_sub(R23, L23));
+                        }
+                        int hh[2], gq[2], cq[2];
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            const int hf = pk_max(hq[q], f[0][q]);
+                            const int h = pk_max(hf, f[1][q]);
+                            const int d1 = pk_minu_c<1>(pk_sub(hf, hq[q])), d2 = pk_minu_c<1>(pk_sub(h, hf));
+                            // direction byte: flags | F1 chosen << 4 | F2 chosen << 5 | F1 opened << 6 | F2 opened << 7
+                            // (bits 6,7 are written inverted by this kernel -- 1 = NOT opened -- the traceback is told so)
+                            int c = pk_mad_c<16>(pk_mad_c<2>(d2, d1), fq[q]);
+                            c = pk_mad_c<64>(pk_mad_c<2>(t[1][q], t[0][q]), c);
+                            cq[q] = c;
+                            const int dh = pk_subs(h, hq[q]);
+                            const int b1 = pk_min(pk_adds(u1q[q], dh), 0x00040004), b2 = pk_min(pk_adds(u2q[q], dh), 0x00180018);
+                            gq[q] = pk_addu_c<10>(pk_mad_c<8>(b2, b1));  // (b1 + e1) | (b2 + e2) << 3
+                            hh[q] = h;
+                        }
+                        // row maximum and the range check run on the active cells only
+                        int hb[2] = {hh[0], hh[1]};
+                        if constexpr (EDGE) {
+                            if (rp) {
+                                int d = j0 - end - 1;
+                                d = d < -64 ? -64 : (d > 64 ? 64 : d);
+                                const int db = pk_bcast(d);
+                                const int in0 = ipk(pk(pk_add(db, 0x00010000)) >> 15), in1 = ipk(pk(pk_add(db, 0x00030002)) >> 15);
+                                hb[0] = (hb[0] & in0) | (SENT & ~in0); hb[1] = (hb[1] & in1) | (SENT & ~in1);
+                            }
+                        }
+                        zacc = pk_minu(zacc, pk_minu(pk_add(hb[0], 0x7d007d00), pk_add(hb[1], 0x7d007d00)));  // + 32000
+                        {
+                            const int pm = pk_max(hb[0], hb[1]);
+                            const int m4p = pk_max(pm, (int)__builtin_amdgcn_perm((uint32_t)pm, (uint32_t)pm, 0x05040706u));  // both halves = max of 4
+                            const int m4 = pk_lo(m4p);
+                            if (m4 >= best) {
+                                // which of the four cells hold it: bit k of nm
+                                const int z0 = pk_minu_c<1>(pk_sub(m4p, hb[0])), z1 = pk_minu_c<1>(pk_sub(m4p, hb[1]));
+                                const uint32_t mb = (uint32_t)z0 | ((uint32_t)z1 << 2);
+                                const uint32_t nm = ((mb | (mb >> 15)) & 15u) ^ 15u;
+                                const int kf = __builtin_ctz(nm), kl = 31 - __builtin_clz(nm);
+                                if (m4 > best) { best = m4; lpos = j0 + kf; }
+                                rpos = j0 + kl;
+                            }
+                        }
+                        if (!EDGE || lane_act) {
+                            const uint32_t gb4 = __builtin_amdgcn_perm((uint32_t)gq[1], (uint32_t)gq[0], 0x06040200u);
+                            const uint32_t cb4 = __builtin_amdgcn_perm((uint32_t)cq[1], (uint32_t)cq[0], 0x06040200u);
+                            if (!wide) {
+                                *(uint2 *)(H16a + (j0 & win_mask)) = make_uint2((uint32_t)hh[0], (uint32_t)hh[1]);
+                                *(uint32_t *)(G8a + (j0 & win_mask)) = gb4;
+                            }
+                            *(uint32_t *)(drow + c) = cb4;
+                            if (keep) {
+                                *(uint2 *)((int16_t *)Vrow + c) = make_uint2((uint32_t)hh[0], (uint32_t)hh[1]);
+                                *(uint32_t *)(Vrow + 2 * (int64_t)W + c) = gb4;
+                            }
+                        }
+                    };
+                    if (__builtin_expect(lp || rp, 0)) phase2h(std::true_type{});
+                    else phase2h(std::false_type{});
+                  } else {
                     // ---------------- interior path, phase 2
                     auto phase2 = [&](auto edge_c) {
                         constexpr bool EDGE = decltype(edge_c)::value;
@@ -1242,6 +1599,12 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                             wv4[k] = (int)(((uint32_t)h << 8) | (uint32_t)(dd1 | (dd2 << g1bits)));
                             int hb = h;
                             if constexpr (EDGE) hb = j > end ? INT32_MIN : h;
+                            if constexpr (H16) {
+                                // a real score must stay above -30 000; the band-edge sentinels sit at or below -32 000
+                                const bool zone = (unsigned)(h + 32000) < 2000u;
+                                if constexpr (EDGE) danger |= (zone && j >= beg && j <= end) ? 1 : 0;
+                                else danger |= zone ? 1 : 0;
+                            }
                             if (hb > best) { best = hb; lpos = j; rpos = j; }
                             else if (hb == best) rpos = j;
                             L1 = ht[k] + e1 * k; L2 = ht[k] + e2 * k;
@@ -1252,15 +1615,16 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                         for (int q = 0; q < QPT; q++) {
                             if (!EDGE || j0 + 4 * q <= end) {
                                 const int4 wq = make_int4(wv4[4 * q], wv4[4 * q + 1], wv4[4 * q + 2], wv4[4 * q + 3]);
-                                if (!wide) *(int4 *)(HG + ((j0 + 4 * q) & win_mask)) = wq;
+                                if (!wide) lds_store(j0 + 4 * q, wq);
                                 *(uint32_t *)(drow + c + 4 * q) = (uint32_t)codev[4 * q] | ((uint32_t)codev[4 * q + 1] << 8) |
                                                                  ((uint32_t)codev[4 * q + 2] << 16) | ((uint32_t)codev[4 * q + 3] << 24);
-                                if (keep) *(int4 *)(Vrow + c + 4 * q) = wq;
+                                if (keep) hbm_store(Vrow, W, c + 4 * q, wq);
                             }
                         }
                     };
                     if (__builtin_expect(lp || rp, 0)) phase2(std::true_type{});
                     else phase2(std::false_type{});
+                  }
         POA_MARK("p2_slow");
                 } else if (lane_act) {
                     int beg_ = beg, end_ = end;  // (cold path: see the note in phase 1)
@@ -1268,6 +1632,15 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                     const int beg = beg_;
                     const unsigned span = (unsigned)(end_ - beg_);
                     int wv4[CPT], codev[CPT];
+                    if constexpr (H16) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int q = k >> 1;
+                            auto half = [&](int v) { return (k & 1) ? (v >> 16) : pk_lo(v); };
+                            ht[k] = half(hq[q]);
+                            meta[k] = (half(fq[q]) & 15) | ((half(u1q[q]) & 255) << 8) | ((half(u2q[q]) & 255) << 16);
+                        }
+                    }
 #pragma unroll
                     for (int k = 0; k < CPT; k++) {
                         const int j = j0 + k;
@@ -1278,7 +1651,7 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                         const int hf = ht[k] > f1 ? ht[k] : f1;
                         const int h = hf > f2 ? hf : f2;
                         const int fsel = f2 > hf ? 32 : (f1 > ht[k] ? 16 : 0);
-                        codev[k] = (meta[k] & 15) | fsel | fo;
+                        codev[k] = ((meta[k] & 15) | fsel | fo) ^ (H16 ? 0xC0 : 0);
                         const int dh = h - ht[k];
                         int dd1 = ((meta[k] >> 8) & 255) + dh; dd1 = (dd1 < o1 ? dd1 : o1) + e1;
                         int dd2 = ((meta[k] >> 16) & 255) + dh; dd2 = (dd2 < o2 ? dd2 : o2) + e2;
@@ -1286,6 +1659,7 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                         const int hb = actk ? h : INT32_MIN;
                         if (hb > best) { best = hb; lpos = j; rpos = j; }
                         else if (actk && hb == best) rpos = j;
+                        if constexpr (H16) danger |= (actk && (unsigned)(h + 32000) < 2000u) ? 1 : 0;
                         const int a1 = actk ? ht[k] + e1 * j : POA_IDENT, a2 = actk ? ht[k] + e2 * j : POA_IDENT;
                         run1 = a1 > run1 ? a1 : run1;
                         run2 = a2 > run2 ? a2 : run2;
@@ -1298,10 +1672,10 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                         if (j0 + 4 * q > end_) continue;  // beyond the row's storage
                         const int4 wq = make_int4(wv4[4 * q], wv4[4 * q + 1], wv4[4 * q + 2], wv4[4 * q + 3]);
                         const int cq = c + 4 * q;
-                        if (!wide) *(int4 *)(HG + ((j0 + 4 * q) & win_mask)) = wq;
+                        if (!wide) lds_store(j0 + 4 * q, wq);
                         *(uint32_t *)(drow + cq) = (uint32_t)codev[4 * q] | ((uint32_t)codev[4 * q + 1] << 8) |
                                                    ((uint32_t)codev[4 * q + 2] << 16) | ((uint32_t)codev[4 * q + 3] << 24);
-                        if (keep) *(int4 *)(Vrow + cq) = wq;
+                        if (keep) hbm_store(Vrow, Wl, cq, wq);
                         if (__builtin_expect(np > 1, 0)) {
                             const int *pm = pmeta + 4 * q;
                             *(uint32_t *)(drow + (uint64_t)Wl + cq) = (uint32_t)(pm[0] & 255) | ((uint32_t)(pm[1] & 255) << 8) | ((uint32_t)(pm[2] & 255) << 16) | ((uint32_t)(pm[3] & 255) << 24);
@@ -1324,7 +1698,12 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
             int rm = best == wb ? rpos : INT32_MIN;
             lm = poa_wave_scan_max(lm);
             rm = poa_wave_scan_max(rm);
-            if (lane == 63) sRed[wv] = make_int4(wb, lm, rm, 0);
+            int dz = 0;
+            if constexpr (H16) {
+                danger |= (((uint32_t)zacc & 0xffffu) < 2000u || ((uint32_t)zacc >> 16) < 2000u) ? 1 : 0;
+                dz = __builtin_amdgcn_ballot_w64(danger != 0) != 0ull ? 1 : 0;
+            }
+            if (lane == 63) sRed[wv] = make_int4(wb, lm, rm, dz);
         }
         POA_LDS_BARRIER();
         {
@@ -1348,9 +1727,18 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
             }
             lpos = -__builtin_amdgcn_readlane(lm, NW - 1);
             rpos = __builtin_amdgcn_readlane(rm, NW - 1);
+            if constexpr (H16) {
+                prev_hmax = rbest + base;
+                prev_base = base;
+                if (__builtin_amdgcn_ballot_w64(rw.w != 0) != 0ull) { range_stop = true; }
+            }
         }
         POA_MARK("row_end");
-        if (tid == 0) { R[r].lmax = lpos; R[r].rmax = rpos; }
+        if (tid == 0) {
+            R[r].lmax = lpos; R[r].rmax = rpos;
+            if constexpr (H16) R[r].hmax = prev_hmax;
+        }
+        if (range_stop) { stop = true; break; }
         prev_beg = beg; prev_end = end; prev_lmax = lpos; prev_rmax = rpos;
         prev_lds = !wide;
         stamp(5);
@@ -1369,7 +1757,11 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
         O.cells = L.cells;
         O.vcells = L.vcells;
         O.maxw = (uint32_t)L.maxw;
-        if (failed) {
+        if (range_stop) {
+            O.status = POA_ST_RANGE;
+            O.score = POA_NEG;
+            O.row = 0;
+        } else if (failed) {
             O.status = POA_ST_POOL;
             O.score = POA_NEG;
             O.row = 0;
@@ -1381,7 +1773,12 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                 const uint32_t p = sink_preds[pb.sink0 + t];
                 const int bp = R[p].beg, ep = R[p].end;
                 int val = POA_NEG;
-                if (qlen >= bp && qlen <= ep) val = ((const int32_t *)(pool + R[p].voff))[qlen - (bp & ~3)] >> 8;
+                if (qlen >= bp && qlen <= ep) {
+                    const int Wq = (ep - (bp & ~3) + 1 + 3) & ~3;
+                    const int wv_ = hbm_word(pool + R[p].voff, Wq, qlen - (bp & ~3)) >> 8;
+                    // (16-bit storage) a sentinel stays a sentinel; a real value is made absolute
+                    val = H16 ? (wv_ <= -30000 ? POA_NEG : wv_ + R[p].base) : wv_;
+                }
                 if (!have || val > bestv) { bestv = val; brow = p; have = true; }
             }
             O.score = bestv;
@@ -1391,10 +1788,10 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
     }
 }
 
-static inline size_t poa_pk_lds_bytes(uint32_t hg_cols, uint32_t lds_cols, int nt)
+static inline size_t poa_pk_lds_bytes(uint32_t hg_cols, uint32_t lds_cols, int nt, bool h16 = false)
 {
     const int nw = nt / 64;
-    return 4ull * hg_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw) * 16 + 16 + 48 + 64 + 16;
+    return (h16 ? 3ull : 4ull) * hg_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw + 1 + 4 + 4) * 16 + 16;
 }
 
 static inline uint32_t poa_lds_cols(uint32_t max_q) { return ((max_q + 1 + 15u) & ~15u) + 16u; }
@@ -1597,7 +1994,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     std::vector<uint32_t> ids;
     auto ensure = [&](uint64_t a, uint64_t b) {
         ids.clear();
-        for (uint64_t i = a; i < b && i < n; i++)
+        for (uint64_t i = a; i < b && i < order.size(); i++)
             if (!ready[order[i]]) ids.push_back(order[i]);
         if (ids.empty()) return;
         if (feed.prepare) feed.prepare(ids.data(), ids.size());
@@ -1675,13 +2072,14 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     P.o2 = params->gap_open2; P.e2 = params->gap_ext2; P.banded = params->wb >= 0;
 
     bool packed_all = true;  // value rows are 4 B per cell with the packed kernel, 6 B otherwise (byte model)
+    bool h16_all = true;     // ... and 3 B with 16-bit row state
     int t_total = vga_timer_begin(ctx, "poa_total", 0);
-    struct sub_t { uint64_t i0, i1; double raw_est; int slot; int oset; };
+    struct sub_t { uint64_t i0, i1; double raw_est; int slot; int oset; bool use32 = false; };
     hipError_t launch_err = hipSuccess;
     uint64_t in_flight_other = 0;  // problems of the sub-batch on the other stream (they share the GPU with this launch)
     // stage, upload and enqueue DP + traceback + result copies of a sub-batch that starts at launch position i0 and ends
     // at cap at the latest
-    auto launch = [&](uint64_t i0, uint64_t cap, int slot) -> sub_t {
+    auto launch = [&](uint64_t i0, uint64_t cap, int slot, bool use32) -> sub_t {
         hipStream_t st = sarr[slot];  // shadows the context's stream inside this lambda
         poa_slot &S = W.slot[slot];
         uint8_t *pool_base = W.pool + (uint64_t)slot * half_pool;
@@ -1698,6 +2096,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             i1++;
         }
         auto chk = [&](hipError_t e) { if (e != hipSuccess && launch_err == hipSuccess) launch_err = e; };
+        bool sub_h16 = false;  // this sub-batch runs the 16-bit DP kernel
         if (malformed || i1 == i0) return {i0, i0, 0.0, slot, 0};
         const int oset = (int)(S.uses++ & 1u);
         poa_slot::out_set &O = S.outs[oset];
@@ -1761,6 +2160,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             while ((1 << g2bits) <= P.o2 + P.e2) g2bits++;
             const bool packed = g1bits + g2bits <= 8 && !(force && strstr(force, "unpacked"));
             packed_all = packed_all && packed;
+            // 16-bit row state (3 B per column): default penalties only; problems it gives up on come back with use32
+            const bool def_pen = P.o1 == 4 && P.e1 == 2 && P.o2 == 24 && P.e2 == 1 && !(force && strstr(force, "generic"));
+            const bool h16 = packed && def_pen && !use32 && getenv("VGA_POA_H16") && atoi(getenv("VGA_POA_H16")) != 0;
+            h16_all = h16_all && h16;
+            sub_h16 = h16;
             // LDS column window (packed kernel): 4096 columns keep almost every row of a 10 kbp read resident (its widest
             // rows, a few per cent, take the HBM detour described in the kernel) and let seven workgroups share a CU
             // instead of three.  Queries that fit a smaller array anyway keep every column.
@@ -1779,11 +2183,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 // workgroup size: the one that keeps the most waves resident (LDS and the 28 wave slots of a CU bound the
                 // workgroups per CU; the problems still to be run -- this sub-batch and the ones that will overlap it --
                 // bound how many there are); ties go to the smaller workgroup, whose barriers are cheaper
-                auto by_lds = [&](int t) { return std::max<size_t>(1, (160 * 1024) / (poa_pk_lds_bytes(hg_cols, lds_cols, t) + 256)); };
+                auto by_lds = [&](int t) { return std::max<size_t>(1, (160 * 1024) / (poa_pk_lds_bytes(hg_cols, lds_cols, t, h16) + 256)); };
                 size_t best_waves = 0;
                 for (int t = 128; t <= 512; t += 64) {
                     const size_t per_cu = std::min<size_t>(by_lds(t), (size_t)((cpt == 8 ? 20 : 28) / (t / 64)));
-                    const size_t waves = std::min<size_t>(n - i0 + in_flight_other, per_cu * (size_t)ctx->n_cu) * (size_t)(t / 64);
+                    const size_t waves = std::min<size_t>(order.size() - i0 + in_flight_other, per_cu * (size_t)ctx->n_cu) * (size_t)(t / 64);
                     if (waves > best_waves) { best_waves = waves; nt = t; }
                 }
                 const char *ent = getenv("VGA_POA_NT");
@@ -1795,12 +2199,12 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 else if (strstr(force, "256")) nt = 256;
                 else if (strstr(force, "512")) nt = 512;
             }
-            auto lds_of = [&](int t) { return packed ? poa_pk_lds_bytes(hg_cols, lds_cols, t) : poa_lds_bytes(lds_cols, t); };
+            auto lds_of = [&](int t) { return packed ? poa_pk_lds_bytes(hg_cols, lds_cols, t, h16) : poa_lds_bytes(lds_cols, t); };
             while (nt > 128 && lds_of(nt) > 160 * 1024 - 256) nt = packed ? nt - 64 : nt / 2;
             const size_t lds = lds_of(nt);
             if (tr.on)
-                fprintf(stderr, "[vga-trace] poa: launch %u problems, NT %d, window %u of %u columns, widest estimate %.0f, LDS %zu B\n",
-                        nb, nt, hg_cols, lds_cols, mw, lds);
+                fprintf(stderr, "[vga-trace] poa: launch %u problems, NT %d, %s, window %u of %u columns, widest estimate %.0f, LDS %zu B\n",
+                        nb, nt, h16 ? "16-bit rows" : "32-bit rows", hg_cols, lds_cols, mw, lds);
 #define POA_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_sink.p, P, S.d_rows.p, pool_base,          \
                  W.d_next.p + slot, half_pool, S.d_outs.p, lds_cols
 #define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, g1bits
@@ -1830,17 +2234,17 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                                 wsel * 2, sum[0], sum[1], sum[6], sum[2], sum[3], sum[4], sum[5], tot);
                     }
                 } else {
-#define POA_PK_LAUNCH2(T, D, C)                                                                                             \
+#define POA_PK_LAUNCH2(T, D, C, H)                                                                                          \
     {                                                                                                                       \
-        chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<T, false, D, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_poa_dp_pk<T, false, D, C>), dim3(nb), dim3(T), lds, st, POA_PK_ARGS);                        \
+        chk(hipFuncSetAttribute((const void *)k_poa_dp_pk<T, false, D, C, H>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_poa_dp_pk<T, false, D, C, H>), dim3(nb), dim3(T), lds, st, POA_PK_ARGS);                     \
     }
 #define POA_PK_LAUNCH(T)                                                                                                    \
     case T:                                                                                                                 \
-        if (def_pen) POA_PK_LAUNCH2(T, true, 4)                                                                             \
-        else POA_PK_LAUNCH2(T, false, 4)                                                                                    \
+        if (h16) POA_PK_LAUNCH2(T, true, 4, true)                                                                           \
+        else if (def_pen) POA_PK_LAUNCH2(T, true, 4, false)                                                                 \
+        else POA_PK_LAUNCH2(T, false, 4, false)                                                                             \
         break;
-                    const bool def_pen = P.o1 == 4 && P.e1 == 2 && P.o2 == 24 && P.e2 == 1 && !(force && strstr(force, "generic"));
                     switch (nt) {
                         POA_PK_LAUNCH(128) POA_PK_LAUNCH(192) POA_PK_LAUNCH(256) POA_PK_LAUNCH(320)
                         POA_PK_LAUNCH(384) POA_PK_LAUNCH(448) POA_PK_LAUNCH(512)
@@ -1866,7 +2270,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         vga_timer_end(ctx, t_dp);
         int t_tb = vga_timer_begin(ctx, "poa_traceback", 0, st);
         hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
-                           pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p);
+                           pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, sub_h16 ? 0xC0 : 0);
         vga_timer_end(ctx, t_tb);
         chk(hipMemcpyAsync(O.h_outs.p, S.d_outs.p, nb * sizeof(poa_out), hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(W.h_next.p + slot, W.d_next.p + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -1879,6 +2283,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         const uint32_t p = order[i];
         poa_item &it = out[p];
         const poa_out &ho = S.h_outs.p[i - i0];
+        if (ho.status == POA_ST_RANGE) return;  // re-run later
         it.ok = ho.status == POA_ST_OK ? 1 : 0;
         it.score = ho.score;
         it.n_cells = ho.cells;
@@ -1948,8 +2353,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     // host threads prepare the problems of the next sub-batch (the caller's subgraphs, node tables) and turn the op
     // streams of the sub-batch that just finished into CIGAR / cs strings.
     int rc_final = VGA_OK;
-    std::vector<std::pair<uint64_t, uint64_t>> todo;  // used as a stack of [begin, end) ranges, front = back()
-    todo.push_back({0, n});
+    struct seg_t { uint64_t first, second; bool use32; };
+    std::vector<seg_t> todo;  // used as a stack of [begin, end) ranges of launch positions, front = back()
+    todo.push_back({0, n, false});
+    std::vector<uint32_t> retry32;  // problems the 16-bit kernel gave up on (POA_ST_RANGE)
     std::vector<sub_t> inflight;
     bool slot_busy[2] = {false, false};
     uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
@@ -1958,7 +2365,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             const int slot = slot_busy[0] ? 1 : 0;
             auto &seg = todo.back();
             in_flight_other = inflight.empty() ? 0 : inflight.front().i1 - inflight.front().i0;
-            sub_t sb = launch(seg.first, seg.second, slot);
+            sub_t sb = launch(seg.first, seg.second, slot, seg.use32);
+            sb.use32 = seg.use32;
             if (sb.i1 == sb.i0) break;
             if (sb.i1 >= seg.second) todo.pop_back();
             else seg.first = sb.i1;
@@ -1982,7 +2390,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             slot_busy[cur.slot] = false;
             if (cur.i1 - cur.i0 == 1 && W.pool_scale >= 8.0) { rc_final = VGA_ERR_POOL; break; }
             W.pool_scale = std::min(16.0, W.pool_scale * 1.7);
-            todo.push_back({cur.i0, cur.i1});  // enqueue it again, in smaller pieces
+            todo.push_back({cur.i0, cur.i1, cur.use32});  // enqueue it again, in smaller pieces
             fill();
             continue;
         }
@@ -2001,6 +2409,16 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             fprintf(stderr, "[vga-trace] poa: sub-batch [%llu, %llu) done, pool %.1f GB, widest row %u columns, worst width / estimate %.3f\n",
                     (unsigned long long)cur.i0, (unsigned long long)cur.i1, (double)W.h_next.p[cur.slot] / 1e9, mx, worst);
         }
+        // problems the 16-bit kernel stopped (a score near the int16 range) run again with 32-bit words
+        for (uint64_t i = cur.i0; i < cur.i1; i++)
+            if (S.h_outs.p[i - cur.i0].status == POA_ST_RANGE) retry32.push_back(order[i]);
+        if (todo.empty() && inflight.empty() && !retry32.empty()) {
+            const uint64_t a = order.size();
+            for (uint32_t p : retry32) order.push_back(p);
+            if (tr.on) fprintf(stderr, "[vga-trace] poa: %zu problems re-run with 32-bit rows\n", retry32.size());
+            retry32.clear();
+            todo.push_back({a, order.size(), true});
+        }
         // refill the GPU first (the new sub-batch's results go to the slot's other result set), then post-process
         slot_busy[cur.slot] = false;
         fill();
@@ -2009,6 +2427,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             parallel_for(cnt, [&](uint64_t t) { post_one(S, a0, a0 + t); });
             for (uint64_t i = cur.i0; i < cur.i1; i++) {
                 const poa_out &ho = S.h_outs.p[i - cur.i0];
+                if (ho.status == POA_ST_RANGE) continue;
                 all_cells += ho.cells; all_vcells += ho.vcells; all_ops += ho.nops;
                 all_rows += G[order[i]].N; all_q += G[order[i]].qlen;
             }
@@ -2029,7 +2448,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     // byte model of the DP kernel: graph bases + query + 1 direction byte per cell
     // + the value rows kept in HBM (4 B per cell packed, 6 B otherwise), written once and read back at least once
     for (auto &a : ctx->last_times) {
-        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + (packed_all ? 8 : 12) * all_vcells;
+        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + (h16_all ? 6 : (packed_all ? 8 : 12)) * all_vcells;
         if (a.name == "poa_traceback") a.bytes = 6 * all_ops;
     }
     tm.ms_dp = vga_timer_sum(ctx, "poa_band_dp");

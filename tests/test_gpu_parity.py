@@ -219,6 +219,26 @@ def test_align_config3_sample(oracle, ctx, drb1):
     _check_align(oracle, ctx, ix, pkg().readsim.config3_reads(DRB1, 3))
 
 
+def test_poa_16bit_row_state_experimental(oracle, ctx, drb1, monkeypatch):
+    """VGA_POA_H16=1: int16 row state relative to a per-row base, packed two-cells-per-instruction interior path.
+    Same results as the oracle; a problem whose scores come near the int16 range is re-run with 32-bit words
+    (unbanded 33 kbp query against a tiny graph: H falls below -30 000 along the first row)."""
+    monkeypatch.setenv("VGA_POA_H16", "1")
+    rng = random.Random(4321)
+    problems = [_rand_problem(rng, rng.randint(1, 40), 6) for _ in range(60)]
+    problems += [_rand_problem(rng, rng.randint(20, 120), 12, qlen_scale=s) for s in (0.3, 1.0) for _ in range(8)]
+    problems += [_rand_problem(rng, 60, 60) for _ in range(3)]
+    _check_poa(oracle, ctx, problems)
+    pp, op = pkg().default_poa_params(), oracle.default_poa_params()
+    pp.wb = -1
+    op.wb = -1
+    long_q = "".join(rng.choice("ACGT") for _ in range(33000))
+    _check_poa(oracle, ctx, [(["ACGT", "TTGA"], [(0, 1)], long_q), (["ACGTACGT"], [], "ACGTTCGT")], pp, op)
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    _check_align(oracle, ctx, ix, pkg().readsim.config3_reads(DRB1, 3))
+
+
 def test_poa_large_gap_penalties_use_the_unpacked_kernel(oracle, ctx):
     """open+extend of the two gap pieces need more than 8 bits together -> k_poa_dp_lds (2-byte gap deltas)"""
     rng = random.Random(7)
