@@ -56,6 +56,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+    # host threads of the library (subgraph extraction, CIGAR strings): share the node's cores between the ranks
+    if world > 1 and "VGA_HOST_THREADS" not in os.environ:
+        os.environ["VGA_HOST_THREADS"] = str(max(4, min(32, (os.cpu_count() or 32) // world)))
+
     import __graft_entry__ as ge
 
     pkg = ge.load_package()
