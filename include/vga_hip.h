@@ -95,6 +95,11 @@ typedef struct {
     uint64_t max_gap;             /* 1000 (map_main.rs:30-34) */
     uint32_t chain_min_n_anchors; /* 3    (map_main.rs:42-46) */
     int only_forward;             /* 1    (src/map.rs:62); 0 is not supported yet */
+    int emit_dp;                  /* 1: the result also carries Anchor.id, f(i) and the best predecessor of every anchor
+                                   *    (what the reference keeps inside chain_anchors; parity checks read them).
+                                   * 0: anchor_id / max_chain_score / best_pred_id are NULL -- the GAF writers and
+                                   *    vga_align_batch only read the anchor coordinates and the chain membership, and
+                                   *    16 of the 40 bytes per anchor stay on the GPU. */
 } vga_map_params;
 void vga_map_default_params(vga_map_params *p);
 
@@ -107,12 +112,12 @@ typedef struct {
     uint64_t n_reads;
     uint64_t n_anchors;
     uint64_t *anchor_off;    /* n_reads+1 */
-    uint32_t *anchor_id;     /* Anchor.id (src/chain.rs:146,162) */
+    uint32_t *anchor_id;     /* Anchor.id (src/chain.rs:146,162); NULL when emit_dp = 0 */
     uint32_t *query_begin;   /* Anchor.query_begin; query_end = query_begin + k */
     uint32_t *target_begin;  /* Anchor.target_begin.position (Forward) */
     uint32_t *target_end;    /* Anchor.target_end.position   (Forward) */
-    double *max_chain_score; /* f(i) after src/chain.rs:403-450 */
-    int32_t *best_pred_id;   /* id of the best predecessor after the DP, VGA_NO_PRED for None */
+    double *max_chain_score; /* f(i) after src/chain.rs:403-450; NULL when emit_dp = 0 */
+    int32_t *best_pred_id;   /* id of the best predecessor after the DP, VGA_NO_PRED for None; NULL when emit_dp = 0 */
     double *curr_max;        /* per read */
     uint64_t n_chains;
     uint64_t *chain_off;        /* n_reads+1 */

@@ -54,7 +54,7 @@ class IndexDesc(C.Structure):
 
 class MapParams(C.Structure):
     _fields_ = [("bandwidth", C.c_uint32), ("max_gap", C.c_uint64), ("chain_min_n_anchors", C.c_uint32),
-                ("only_forward", C.c_int)]
+                ("only_forward", C.c_int), ("emit_dp", C.c_int)]
 
 
 class PoaParams(C.Structure):
@@ -174,12 +174,12 @@ class MapOut:
         R, A, nc = int(r.n_reads), int(r.n_anchors), int(r.n_chains)
         self.n_reads, self.n_anchors, self.n_chains = R, A, nc
         self.anchor_off = _np(r.anchor_off, R + 1, np.uint64)
-        self.anchor_id = _np(r.anchor_id, A, np.uint32)
+        self.anchor_id = _np(r.anchor_id, A, np.uint32) if r.anchor_id else None  # None with emit_dp = 0
         self.query_begin = _np(r.query_begin, A, np.uint32)
         self.target_begin = _np(r.target_begin, A, np.uint32)
         self.target_end = _np(r.target_end, A, np.uint32)
-        self.max_chain_score = _np(r.max_chain_score, A, np.float64)
-        self.best_pred_id = _np(r.best_pred_id, A, np.int32)
+        self.max_chain_score = _np(r.max_chain_score, A, np.float64) if r.max_chain_score else None
+        self.best_pred_id = _np(r.best_pred_id, A, np.int32) if r.best_pred_id else None
         self.curr_max = _np(r.curr_max, R, np.float64)
         self.chain_off = _np(r.chain_off, R + 1, np.uint64)
         self.chain_placeholder = _np(r.chain_placeholder, nc, np.uint8)
@@ -294,7 +294,10 @@ class Batch:
         Returns counters only."""
         import time as _t
         L = self.ctx.L
-        mp = map_params or default_map_params()
+        mp = map_params
+        if mp is None:
+            mp = default_map_params()
+            mp.emit_dp = 0  # nothing downstream of the chains reads ids / f(i) / predecessors
         pp = poa_params or default_poa_params()
         m = _P(MapResult)()
         t0 = _t.perf_counter()

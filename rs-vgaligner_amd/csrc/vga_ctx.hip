@@ -337,6 +337,7 @@ extern "C" void vga_map_default_params(vga_map_params *p)
     p->max_gap = 1000;
     p->chain_min_n_anchors = 3;
     p->only_forward = 1;
+    p->emit_dp = 1;
 }
 
 extern "C" void vga_poa_default_params(vga_poa_params *p)

@@ -496,27 +496,33 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
 
     tr.mark("launches");
     // ---- results to host: async copies into pinned staging, then a threaded fan-out into the result arrays
-    MAP_CHECK(ws.h_id.reserve(An)); MAP_CHECK(ws.h_qb.reserve(An)); MAP_CHECK(ws.h_tb.reserve(An)); MAP_CHECK(ws.h_te.reserve(An));
-    MAP_CHECK(ws.h_f.reserve(An)); MAP_CHECK(ws.h_pred.reserve(An)); MAP_CHECK(ws.h_chain_buf.reserve(3 * An + 2 * R + 2));
+    const bool emit_dp = params->emit_dp != 0;
+    MAP_CHECK(ws.h_qb.reserve(An)); MAP_CHECK(ws.h_tb.reserve(An)); MAP_CHECK(ws.h_te.reserve(An));
+    if (emit_dp) { MAP_CHECK(ws.h_id.reserve(An)); MAP_CHECK(ws.h_f.reserve(An)); MAP_CHECK(ws.h_pred.reserve(An)); }
+    MAP_CHECK(ws.h_chain_buf.reserve(3 * An + 2 * R + 2));
     MAP_CHECK(ws.h_curr_max.reserve(R)); MAP_CHECK(ws.h_chain_cnt.reserve(R)); MAP_CHECK(ws.h_chain_words.reserve(R));
     if (An) {
-        MAP_CHECK(hipMemcpyAsync(ws.h_id.p, perm, An * 4, hipMemcpyDeviceToHost, st));
+        if (emit_dp) MAP_CHECK(hipMemcpyAsync(ws.h_id.p, perm, An * 4, hipMemcpyDeviceToHost, st));
         MAP_CHECK(hipMemcpyAsync(ws.h_qb.p, ws.s_qb.p, An * 4, hipMemcpyDeviceToHost, st));
         MAP_CHECK(hipMemcpyAsync(ws.h_tb.p, ws.s_tb.p, An * 4, hipMemcpyDeviceToHost, st));
         MAP_CHECK(hipMemcpyAsync(ws.h_te.p, ws.s_te.p, An * 4, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(ws.h_f.p, ws.f.p, An * 8, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(ws.h_pred.p, ws.pred_id.p, An * 4, hipMemcpyDeviceToHost, st));
+        if (emit_dp) {
+            MAP_CHECK(hipMemcpyAsync(ws.h_f.p, ws.f.p, An * 8, hipMemcpyDeviceToHost, st));
+            MAP_CHECK(hipMemcpyAsync(ws.h_pred.p, ws.pred_id.p, An * 4, hipMemcpyDeviceToHost, st));
+        }
         MAP_CHECK(hipMemcpyAsync(ws.h_chain_buf.p, ws.chain_buf.p, (3 * An + 2 * R) * 4, hipMemcpyDeviceToHost, st));
     }
     MAP_CHECK(hipMemcpyAsync(ws.h_curr_max.p, ws.curr_max.p, R * 8, hipMemcpyDeviceToHost, st));
     MAP_CHECK(hipMemcpyAsync(ws.h_chain_cnt.p, ws.chain_cnt.p, R * 4, hipMemcpyDeviceToHost, st));
     MAP_CHECK(hipMemcpyAsync(ws.h_chain_words.p, ws.chain_words.p, R * 4, hipMemcpyDeviceToHost, st));
-    res->anchor_id = xmalloc<uint32_t>(An);
+    if (emit_dp) {
+        res->anchor_id = xmalloc<uint32_t>(An);
+        res->max_chain_score = xmalloc<double>(An);
+        res->best_pred_id = xmalloc<int32_t>(An);
+    }
     res->query_begin = xmalloc<uint32_t>(An);
     res->target_begin = xmalloc<uint32_t>(An);
     res->target_end = xmalloc<uint32_t>(An);
-    res->max_chain_score = xmalloc<double>(An);
-    res->best_pred_id = xmalloc<int32_t>(An);
     MAP_CHECK(hipStreamSynchronize(st));
     tr.mark("kernels + D2H");
     vga_timers_collect(ctx);
@@ -526,6 +532,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
             const uint64_t arr = job / NCH, ch = job % NCH;
             const uint64_t lo = An * ch / NCH, hi = An * (ch + 1) / NCH;
             if (hi <= lo) return;
+            if (!emit_dp && (arr == 0 || arr >= 4)) return;
             switch (arr) {
             case 0: memcpy(res->anchor_id + lo, ws.h_id.p + lo, (hi - lo) * 4); break;
             case 1: memcpy(res->query_begin + lo, ws.h_qb.p + lo, (hi - lo) * 4); break;

@@ -115,6 +115,7 @@ MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequen
     mp.bandwidth = (uint32_t)opt.bandwidth;
     mp.max_gap = opt.max_gap;
     mp.chain_min_n_anchors = (uint32_t)opt.chain_min_n_anchors;
+    mp.emit_dp = 0;  // the GAF writers read anchor coordinates and chain membership only
     vga_map_result *m = nullptr;
     if (vga_map_batch(b, &mp, &m) != VGA_OK) { vga_batch_destroy(b); throw Error(vga_last_error(ctx)); }
     out.n_anchors = m->n_anchors;

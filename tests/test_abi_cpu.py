@@ -21,14 +21,14 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(p.binding.ABI_SYMBOLS), declared ^ set(p.binding.ABI_SYMBOLS)
     for sym in sorted(declared):
         assert hasattr(L, sym), f"libvga_hip.so does not export {sym}"
-    assert L.vga_abi_version() == 2
+    assert L.vga_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
     p = pkg()
     b = p.binding
     assert C.sizeof(b.KmerPos) == 24
-    assert C.sizeof(b.MapParams) == 24
+    assert C.sizeof(b.MapParams) == 32
     assert C.sizeof(b.PoaParams) == 40
     assert b.KMERPOS_DTYPE.itemsize == 24
 

@@ -219,6 +219,23 @@ def test_align_config3_sample(oracle, ctx, drb1):
     _check_align(oracle, ctx, ix, pkg().readsim.config3_reads(DRB1, 3))
 
 
+def test_map_without_dp_arrays_feeds_the_same_alignments(oracle, ctx, drb1):
+    """vga_map_params.emit_dp = 0: ids / f(i) / predecessors stay on the GPU, chains and alignments are unchanged"""
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    reads = pkg().readsim.config2_reads(DRB1, 40)
+    b = ctx.batch([r.seq for r in reads])
+    full = b.map()
+    mp = pkg().default_map_params()
+    mp.emit_dp = 0
+    lean = b.map(mp)
+    assert lean.anchor_id is None and lean.max_chain_score is None and lean.best_pred_id is None
+    assert lean.query_begin.tolist() == full.query_begin.tolist() and lean.target_end.tolist() == full.target_end.tolist()
+    assert lean.chain_anchor_idx.tolist() == full.chain_anchor_idx.tolist()
+    a1, a2 = b.align(full), b.align(lean)
+    assert a1.cigar == a2.cigar and a1.cs == a2.cs and a1.path_handles.tolist() == a2.path_handles.tolist()
+
+
 def test_poa_16bit_row_state_experimental(oracle, ctx, drb1, monkeypatch):
     """VGA_POA_H16=1: int16 row state relative to a per-row base, packed two-cells-per-instruction interior path.
     Same results as the oracle; a problem whose scores come near the int16 range is re-run with 32-bit words
