@@ -339,6 +339,14 @@ struct map_ws {
     vga_hbuf<uint32_t> h_id, h_qb, h_tb, h_te, h_chain_buf, h_chain_cnt, h_chain_words, h_cnt;
     vga_hbuf<double> h_f, h_curr_max;
     vga_hbuf<int32_t> h_pred;
+    // the sorted anchor coordinates go back to the host on a second stream while the chaining kernel runs
+    hipStream_t st_copy = nullptr;
+    hipEvent_t ev_sorted = nullptr;
+    ~map_ws()
+    {
+        if (st_copy) (void)hipStreamDestroy(st_copy);
+        if (ev_sorted) (void)hipEventDestroy(ev_sorted);
+    }
 };
 
 template <typename T>
@@ -485,6 +493,19 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     hipLaunchKernelGGL(k_anchor_gather_seg, dim3((unsigned)R), dim3(256), 0, st, ws.anchor_off.p, perm, ws.a_qb.p, ws.a_tb.p,
                        ws.a_te.p, ws.s_qb.p, ws.s_tb.p, ws.s_te.p);
     vga_timer_end(ctx, t3);
+    // the sorted coordinates are final: copy them back next to the chaining kernel
+    if (!ws.st_copy) {
+        MAP_CHECK(hipStreamCreateWithFlags(&ws.st_copy, hipStreamNonBlocking));
+        MAP_CHECK(hipEventCreateWithFlags(&ws.ev_sorted, hipEventDisableTiming));
+    }
+    MAP_CHECK(ws.h_qb.reserve(An)); MAP_CHECK(ws.h_tb.reserve(An)); MAP_CHECK(ws.h_te.reserve(An));
+    MAP_CHECK(hipEventRecord(ws.ev_sorted, st));
+    MAP_CHECK(hipStreamWaitEvent(ws.st_copy, ws.ev_sorted, 0));
+    if (An) {
+        MAP_CHECK(hipMemcpyAsync(ws.h_qb.p, ws.s_qb.p, An * 4, hipMemcpyDeviceToHost, ws.st_copy));
+        MAP_CHECK(hipMemcpyAsync(ws.h_tb.p, ws.s_tb.p, An * 4, hipMemcpyDeviceToHost, ws.st_copy));
+        MAP_CHECK(hipMemcpyAsync(ws.h_te.p, ws.s_te.p, An * 4, hipMemcpyDeviceToHost, ws.st_copy));
+    }
 
     // ---- K3: chain DP + backtracking
     int t4 = vga_timer_begin(ctx, "chain_dp", 16 * total + 12 * total);
@@ -497,15 +518,11 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     tr.mark("launches");
     // ---- results to host: async copies into pinned staging, then a threaded fan-out into the result arrays
     const bool emit_dp = params->emit_dp != 0;
-    MAP_CHECK(ws.h_qb.reserve(An)); MAP_CHECK(ws.h_tb.reserve(An)); MAP_CHECK(ws.h_te.reserve(An));
     if (emit_dp) { MAP_CHECK(ws.h_id.reserve(An)); MAP_CHECK(ws.h_f.reserve(An)); MAP_CHECK(ws.h_pred.reserve(An)); }
     MAP_CHECK(ws.h_chain_buf.reserve(3 * An + 2 * R + 2));
     MAP_CHECK(ws.h_curr_max.reserve(R)); MAP_CHECK(ws.h_chain_cnt.reserve(R)); MAP_CHECK(ws.h_chain_words.reserve(R));
     if (An) {
         if (emit_dp) MAP_CHECK(hipMemcpyAsync(ws.h_id.p, perm, An * 4, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(ws.h_qb.p, ws.s_qb.p, An * 4, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(ws.h_tb.p, ws.s_tb.p, An * 4, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(ws.h_te.p, ws.s_te.p, An * 4, hipMemcpyDeviceToHost, st));
         if (emit_dp) {
             MAP_CHECK(hipMemcpyAsync(ws.h_f.p, ws.f.p, An * 8, hipMemcpyDeviceToHost, st));
             MAP_CHECK(hipMemcpyAsync(ws.h_pred.p, ws.pred_id.p, An * 4, hipMemcpyDeviceToHost, st));
@@ -524,6 +541,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     res->target_begin = xmalloc<uint32_t>(An);
     res->target_end = xmalloc<uint32_t>(An);
     MAP_CHECK(hipStreamSynchronize(st));
+    MAP_CHECK(hipStreamSynchronize(ws.st_copy));
     tr.mark("kernels + D2H");
     vga_timers_collect(ctx);
     {
@@ -550,25 +568,28 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     // ---- chains: discovery order per read, members reversed to ascending (src/chain.rs:546);
     // a read without chains gets one placeholder (src/chain.rs:644-649)
     uint64_t n_chains = 0, n_members = 0;
+    std::vector<uint64_t> mem0(R);  // first member slot of each read
     for (uint64_t r = 0; r < R; r++) {
         uint32_t c = h_chain_cnt[r];
+        res->chain_off[r] = n_chains;
+        mem0[r] = n_members;
         n_chains += c ? c : 1;
         n_members += h_chain_words[r] - c;
     }
+    res->chain_off[R] = n_chains;
     res->n_chains = n_chains;
     res->chain_placeholder = xmalloc<uint8_t>(n_chains);
     res->chain_anchor_off = xmalloc<uint64_t>(n_chains + 1);
     res->chain_anchor_idx = xmalloc<uint32_t>(n_members);
-    uint64_t ci = 0, mi = 0;
-    for (uint64_t r = 0; r < R; r++) {
-        res->chain_off[r] = ci;
+    res->chain_anchor_off[n_chains] = n_members;
+    vga_parallel_for(R, [&](uint64_t r) {
+        uint64_t ci = res->chain_off[r], mi = mem0[r];
         const uint32_t *buf = h_chain_buf + 3 * res->anchor_off[r] + 2 * r;
         uint32_t c = h_chain_cnt[r], wp = 0;
         if (c == 0) {
             res->chain_placeholder[ci] = 1;
             res->chain_anchor_off[ci] = mi;
-            ci++;
-            continue;
+            return;
         }
         for (uint32_t q = 0; q < c; q++) {
             uint32_t len = buf[wp++];
@@ -579,9 +600,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
             mi += len;
             ci++;
         }
-    }
-    res->chain_off[R] = ci;
-    res->chain_anchor_off[ci] = mi;
+    });
     tr.mark("chain assembly");
     res->ms_probe = vga_timer_sum(ctx, "kmer_probe");
     res->ms_sort = vga_timer_sum(ctx, "anchor_sort");
