@@ -34,6 +34,7 @@
 #define POA_NEG (-(1 << 21))  // "minus infinity"; H stays inside 23 signed bits (see k_poa_dp_pk)
 #define POA_IDENT (INT32_MIN / 2)
 #define POA_CHUNK (1ull << 20)
+#define POA_SLOTS 4  // most sub-batches in flight (VGA_POA_SLOTS; default 2): own stream, pool segment and staging buffers each
 
 #define POA_ST_OK 0
 #define POA_ST_POOL 1
@@ -1903,17 +1904,18 @@ struct poa_slot {
 };
 
 struct poa_ws {
-    poa_slot slot[2];
+    poa_slot slot[POA_SLOTS];
     vga_dbuf<unsigned long long> d_next;
     vga_hbuf<unsigned long long> h_next;
     uint8_t *pool = nullptr;
     uint64_t pool_size = 0;
-    hipStream_t st2 = nullptr;   // sub-batches alternate between the context's stream and this one
+    hipStream_t extra[POA_SLOTS] = {};  // streams of slots 1.. (slot 0 runs on the context's stream)
     double pool_scale = 1.0;   // measured pool bytes / estimated bytes, adapted after every sub-batch
     ~poa_ws()
     {
         if (pool) (void)hipFree(pool);
-        if (st2) (void)hipStreamDestroy(st2);
+        for (int i = 0; i < POA_SLOTS; i++)
+            if (extra[i]) (void)hipStreamDestroy(extra[i]);
     }
 };
 
@@ -2032,8 +2034,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             return vga_set_error(ctx, VGA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
                                  __LINE__);                                                          \
     } while (0)
-    POA_CHECK(W.h_next.reserve(2));
-    POA_CHECK(W.d_next.reserve(2));
+    POA_CHECK(W.h_next.reserve(POA_SLOTS));
+    POA_CHECK(W.d_next.reserve(POA_SLOTS));
     // ---- the pool: sized from the first prepared problems, grown generously (a hipMalloc of this size costs seconds)
     const uint64_t n_probe = std::min<uint64_t>(n, 512);
     ensure(0, n_probe);
@@ -2063,9 +2065,16 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     // Two sub-batches are in flight at any time, one per stream, each carving from its own half of the pool: while one
     // drains (its last workgroups, then the latency-bound traceback and the copies back) the other one's
     // workgroups fill the CUs.
-    if (!W.st2) POA_CHECK(hipStreamCreateWithFlags(&W.st2, hipStreamNonBlocking));
-    hipStream_t sarr[2] = {st, W.st2};
-    const uint64_t half_pool = (W.pool_size / 2) & ~(POA_CHUNK - 1);
+    // two sub-batches in flight; measured on config 3: three are no faster, four overflow their pool quarters
+    int n_slots = 2;
+    if (const char *e = getenv("VGA_POA_SLOTS")) n_slots = std::max(1, std::min(POA_SLOTS, atoi(e)));
+    hipStream_t sarr[POA_SLOTS];
+    sarr[0] = st;
+    for (int i = 1; i < n_slots; i++) {
+        if (!W.extra[i]) POA_CHECK(hipStreamCreateWithFlags(&W.extra[i], hipStreamNonBlocking));
+        sarr[i] = W.extra[i];
+    }
+    const uint64_t half_pool = (W.pool_size / (uint64_t)n_slots) & ~(POA_CHUNK - 1);  // one slot's segment of the pool
 
     poa_dev_params P;
     P.match = params->match; P.mismatch = params->mismatch; P.o1 = params->gap_open1; P.e1 = params->gap_ext1;
@@ -2358,13 +2367,15 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     todo.push_back({0, n, false});
     std::vector<uint32_t> retry32;  // problems the 16-bit kernel gave up on (POA_ST_RANGE)
     std::vector<sub_t> inflight;
-    bool slot_busy[2] = {false, false};
+    bool slot_busy[POA_SLOTS] = {};
     uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
     auto fill = [&]() {
-        while (inflight.size() < 2 && !todo.empty() && !malformed && launch_err == hipSuccess) {
-            const int slot = slot_busy[0] ? 1 : 0;
+        while ((int)inflight.size() < n_slots && !todo.empty() && !malformed && launch_err == hipSuccess) {
+            int slot = 0;
+            while (slot_busy[slot]) slot++;
             auto &seg = todo.back();
-            in_flight_other = inflight.empty() ? 0 : inflight.front().i1 - inflight.front().i0;
+            in_flight_other = 0;
+            for (const sub_t &o : inflight) in_flight_other += o.i1 - o.i0;
             sub_t sb = launch(seg.first, seg.second, slot, seg.use32);
             sb.use32 = seg.use32;
             if (sb.i1 == sb.i0) break;
@@ -2434,7 +2445,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         }
     }
     // drain both streams (also on the error paths: the slots belong to the context)
-    (void)hipStreamSynchronize(W.st2);
+    for (int i = 1; i < n_slots; i++) (void)hipStreamSynchronize(sarr[i]);
     (void)hipStreamSynchronize(st);
     if (launch_err != hipSuccess) return vga_set_error(ctx, VGA_ERR_HIP, "POA launch failed: %s", hipGetErrorString(launch_err));
     if (malformed) return malformed_error();
