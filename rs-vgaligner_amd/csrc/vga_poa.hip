@@ -67,13 +67,14 @@ struct poa_row {          // per DP row, 48 B
                           // hmax = the row maximum (absolute).  0 / unused otherwise.
 };
 
-struct poa_out {          // per problem, 40 B
+struct poa_out {          // per problem, 56 B
     int32_t score;
     uint32_t row;         // sink predecessor the traceback starts from
     int32_t status;
     uint32_t maxw;        // widest row (storage columns)
     uint64_t cells, vcells;
     uint32_t nops, pad;
+    uint64_t t_begin, t_end;  // s_memrealtime (100 MHz) when the DP workgroup started / finished: occupancy diagnostics
 };
 
 struct poa_dev_params {
@@ -816,6 +817,7 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
         }
     };
 
+    const uint64_t t_begin = __builtin_amdgcn_s_memrealtime();
     const poa_prob pb = probs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qlen = (int)pb.qlen;
@@ -1755,6 +1757,8 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
         const lead_t L = lead_load();
         const bool failed = L.failed != 0;
         poa_out &O = outs[blockIdx.x];
+        O.t_begin = t_begin;
+        O.t_end = __builtin_amdgcn_s_memrealtime();
         O.cells = L.cells;
         O.vcells = L.vcells;
         O.maxw = (uint32_t)L.maxw;
@@ -2417,8 +2421,16 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 worst = std::max(worst, (double)S.h_outs.p[i - cur.i0].maxw / estw[order[i]]);
                 mx = std::max(mx, S.h_outs.p[i - cur.i0].maxw);
             }
-            fprintf(stderr, "[vga-trace] poa: sub-batch [%llu, %llu) done, pool %.1f GB, widest row %u columns, worst width / estimate %.3f\n",
-                    (unsigned long long)cur.i0, (unsigned long long)cur.i1, (double)W.h_next.p[cur.slot] / 1e9, mx, worst);
+            uint64_t tb = ~0ull, te = 0, tsum = 0;
+            for (uint64_t i = cur.i0; i < cur.i1; i++) {
+                const poa_out &ho = S.h_outs.p[i - cur.i0];
+                if (ho.t_end > ho.t_begin) { tb = std::min(tb, ho.t_begin); te = std::max(te, ho.t_end); tsum += ho.t_end - ho.t_begin; }
+            }
+            fprintf(stderr, "[vga-trace] poa: sub-batch [%llu, %llu) done, pool %.1f GB, widest row %u columns, worst width / estimate %.3f; "
+                            "DP %.1f ms, mean %.1f workgroups resident, on GPU clock %.3f .. %.3f s\n",
+                    (unsigned long long)cur.i0, (unsigned long long)cur.i1, (double)W.h_next.p[cur.slot] / 1e9, mx, worst,
+                    te > tb ? (double)(te - tb) / 1e5 : 0.0, te > tb ? (double)tsum / (double)(te - tb) : 0.0, (double)(tb % 100000000000ull) / 1e8,
+                    (double)(te % 100000000000ull) / 1e8);
         }
         // problems the 16-bit kernel stopped (a score near the int16 range) run again with 32-bit words
         for (uint64_t i = cur.i0; i < cur.i1; i++)
