@@ -34,6 +34,7 @@
 #define POA_NEG (-(1 << 21))  // "minus infinity"; H stays inside 23 signed bits (see k_poa_dp_pk)
 #define POA_IDENT (INT32_MIN / 2)
 #define POA_CHUNK (1ull << 20)
+#define POA_RING_SPAN 32  // value rows read within this many nodes live in the per-problem ring, the others are kept
 #define POA_SLOTS 4  // most sub-batches in flight (VGA_POA_SLOTS; default 2): own stream, pool segment and staging buffers each
 
 #define POA_ST_OK 0
@@ -55,7 +56,7 @@ struct poa_prob {
     uint32_t N;
     uint32_t w;      // adaptive band half-width: wb + floor(wf * qlen), computed on the host in double
     uint32_t n_nodes;  // node-table entries incl. the source
-    uint32_t pad;
+    uint32_t ring_rows;  // value rows of node-end rows live in a ring of this many worst-case rows (k_poa_dp_pk)
 };
 
 struct poa_row {          // per DP row, 48 B
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
         const bool last = tn + 1 == nlen;
         const int np = v == 0 ? 0 : (tn == 0 ? (int)(nt.y >> 24) : 1);
         const uint32_t ps = nt.w;
-        const int remain = (int)nt.z + (int)(nlen - 1 - tn);
+        const int remain = (int)(nt.z & 0x3fffffffu) + (int)(nlen - 1 - tn);
         uint8_t gb = 0;
         if (v > 0) {
             // row r is base r-1 of the problem's node sequences (seq0 is 4-aligned): one scalar dword per 4 rows
@@ -752,8 +753,9 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
     int4 *sRed = sX + 2 * NW;                 // [NW] {row max, -leftmost, rightmost, 0} per wave
     int32_t *edgeW = (int32_t *)(sRed + NW);  // [2] (+2 pad)
     int4 *sRow = (int4 *)(edgeW + 4);         // [4] the row's parameters, written by wave 0 (see the row loop)
-    int4 *sLead = sRow + 4;                   // [4] wave 0's allocator state and counters
-    constexpr int HDR = (3 * NW + 1 + 4 + 4) * 16;
+    int4 *sLead = sRow + 4;                   // [6] wave 0's allocator state and counters
+    int32_t *sSink = (int32_t *)(sLead + 6);  // [1] (+3 pad) column qlen of a row that feeds the sink, parked by the lane that owns it
+    constexpr int HDR = (3 * NW + 1 + 4 + 6 + 1) * 16;
     int32_t *HG = (int32_t *)(smem + HDR);                       // [hg_cols] (H << 8) | g            (32-bit storage)
     int16_t *H16a = (int16_t *)(smem + HDR);                     // [hg_cols] H - row base            (16-bit storage)
     uint8_t *G8a = smem + HDR + 2ull * hg_cols;                  // [hg_cols] g
@@ -852,11 +854,18 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
     struct lead_t {
         uint64_t dcur, dend, vcur, vendp, wide_scratch, cells, vcells;
         int maxw, failed;
+        // value rows of node-end rows: a ring of ring_size bytes at ring_base (see the leader block)
+        uint64_t ring_base;
+        uint32_t ring_head, ring_size;
+        // best sink candidate so far (rows are visited in the order of the sink list; the first maximum wins)
+        int sink_best, sink_have;
+        uint32_t sink_row;
     };
     auto lead_load = [&]() -> lead_t {
-        const int4 a = sLead[0], b = sLead[1], c = sLead[2], d = sLead[3];
+        const int4 a = sLead[0], b = sLead[1], c = sLead[2], d = sLead[3], e = sLead[4], f = sLead[5];
         auto u64 = [](int lo, int hi) { return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; };
-        return {u64(a.x, a.y), u64(a.z, a.w), u64(b.x, b.y), u64(b.z, b.w), u64(c.x, c.y), u64(c.z, c.w), u64(d.x, d.y), d.z, d.w};
+        return {u64(a.x, a.y), u64(a.z, a.w), u64(b.x, b.y), u64(b.z, b.w), u64(c.x, c.y), u64(c.z, c.w), u64(d.x, d.y), d.z, d.w,
+                u64(e.x, e.y), (uint32_t)e.z, (uint32_t)e.w, f.x, f.y, (uint32_t)f.z};
     };
     auto lead_store = [&](const lead_t &L) {
         if (lane == 0) {
@@ -864,6 +873,8 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
             sLead[1] = make_int4((int)(uint32_t)L.vcur, (int)(uint32_t)(L.vcur >> 32), (int)(uint32_t)L.vendp, (int)(uint32_t)(L.vendp >> 32));
             sLead[2] = make_int4((int)(uint32_t)L.wide_scratch, (int)(uint32_t)(L.wide_scratch >> 32), (int)(uint32_t)L.cells, (int)(uint32_t)(L.cells >> 32));
             sLead[3] = make_int4((int)(uint32_t)L.vcells, (int)(uint32_t)(L.vcells >> 32), L.maxw, L.failed);
+            sLead[4] = make_int4((int)(uint32_t)L.ring_base, (int)(uint32_t)(L.ring_base >> 32), (int)L.ring_head, (int)L.ring_size);
+            sLead[5] = make_int4(L.sink_best, L.sink_have, (int)L.sink_row, 0);
         }
     };
     auto take_chunk = [&](lead_t &L, uint64_t &cur, uint64_t &end) {  // wave 0 only
@@ -904,9 +915,25 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
     const bool q_plain = __syncthreads_or(non_acgt) == 0;
 
     if (leader) {
-        lead_t L = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        lead_t L = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, POA_NEG, 0, 0};
         // two scratch value rows for rows wider than the LDS window (they only feed the row directly below)
         if (win_mask != 0xFFFFFFFFu) L.wide_scratch = alloc(L, L.vcur, L.vendp, 2ull * VB * lds_cols);
+        // The value row of a node's last base is read by the first rows of that node's successors only.  No edge spans
+        // more than ring_rows - 1 nodes except the ones the host marked as long-lived (those rows are kept for good), so a
+        // ring of ring_rows worst-case rows never overwrites a row that is still needed -- and a problem holds ~1 MB of
+        // value rows instead of ~28 MB, which is what lets twice as many problems share the pool.
+        {
+            const uint64_t maxrow = ((uint64_t)VB * (uint64_t)((qlen + 8) & ~3) + 15ull) & ~15ull;
+            const uint64_t rb = (maxrow * (uint64_t)pb.ring_rows + POA_CHUNK - 1) & ~(POA_CHUNK - 1);
+            unsigned long long bv = 0;
+            if (lane == 0) bv = atomicAdd(pool_next, (unsigned long long)rb);
+            const uint64_t b = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(bv >> 32)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv);
+            if (b + rb > pool_size || rb >= (1ull << 32)) L.failed = 1;
+            L.ring_base = b;
+            L.ring_size = (uint32_t)(maxrow * (uint64_t)pb.ring_rows);
+            L.ring_head = 0;
+        }
         lead_store(L);
     }
     int prev_beg = 0, prev_end = -1, prev_lmax = 0, prev_rmax = 0;
@@ -925,6 +952,7 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
         const uint32_t r = nt.x + tn;
         const bool first = tn == 0 && v > 0;
         const bool last = tn + 1 == nlen;
+        const bool is_sink = last && (nt.z >> 31) != 0;  // this row is a predecessor of the sink
         const int np = v == 0 ? 0 : (tn == 0 ? (int)(nt.y >> 24) : 1);
         const uint32_t ps = nt.w;
         uint8_t gb = 0;
@@ -949,7 +977,8 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
         // ---- wave 0: band, pool space, row record
         if (leader) {
             lead_t L = lead_load();
-            const int remain = (int)nt.z + (int)(nlen - 1 - tn);
+            const int remain = (int)(nt.z & 0x3fffffffu) + (int)(nlen - 1 - tn);
+            if (lane == 0) sSink[0] = 0;  // (rewritten in phase 2 by the lane that owns column qlen of a sink row)
             int mpl, mpr;
             if (r == 0) { mpl = 0; mpr = 0; }
             else if (!first) { mpl = prev_lmax + 1; mpr = prev_rmax + 1; }
@@ -983,8 +1012,16 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
             if (last || wide) L.vcells += (uint64_t)(end - beg + 1);
             const uint64_t doff = alloc(L, L.dcur, L.dend, (uint64_t)W * (np > 1 ? 4u : 1u));
             uint64_t voff = 0;
-            if (last && !L.failed) voff = alloc(L, L.vcur, L.vendp, (uint64_t)VB * (uint64_t)W);
-            else if (wide) voff = L.wide_scratch + (r & 1u) * (uint64_t)VB * lds_cols;
+            if (last && !L.failed) {
+                // kept for good: the source row (every root reads it) and rows that are read far ahead
+                if (r == 0 || (nt.z & 0x40000000u)) voff = alloc(L, L.vcur, L.vendp, (uint64_t)VB * (uint64_t)W);
+                else {
+                    const uint32_t bytes = ((uint32_t)VB * (uint32_t)W + 15u) & ~15u;
+                    if (L.ring_head + bytes > L.ring_size) L.ring_head = 0;
+                    voff = L.ring_base + L.ring_head;
+                    L.ring_head += bytes;
+                }
+            } else if (wide) voff = L.wide_scratch + (r & 1u) * (uint64_t)VB * lds_cols;
             int pbeg = prev_beg, pend = prev_end;
             uint64_t vpo = 0;
             // (16-bit storage) this row's base = the largest maximum among its predecessors; dlt = what to add to the
@@ -1565,6 +1602,13 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                                 rpos = j0 + kl;
                             }
                         }
+                        if (__builtin_expect(is_sink, 0)) {
+                            const int kq = qlen - j0;
+                            if (kq >= 0 && kq < 4) {
+                                const int hv_ = kq < 2 ? hh[0] : hh[1];
+                                sSink[0] = ((kq & 1) ? (hv_ >> 16) : pk_lo(hv_)) << 8;
+                            }
+                        }
                         if (!EDGE || lane_act) {
                             const uint32_t gb4 = __builtin_amdgcn_perm((uint32_t)gq[1], (uint32_t)gq[0], 0x06040200u);
                             const uint32_t cb4 = __builtin_amdgcn_perm((uint32_t)cq[1], (uint32_t)cq[0], 0x06040200u);
@@ -1613,6 +1657,12 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                             L1 = ht[k] + e1 * k; L2 = ht[k] + e2 * k;
                             R1 = L1 > R1 ? L1 : R1;
                             R2 = L2 > R2 ? L2 : R2;
+                        }
+                        if (__builtin_expect(is_sink, 0)) {
+                            const int kq = qlen - j0;
+#pragma unroll
+                            for (int k = 0; k < CPT; k++)
+                                if (kq == k) sSink[0] = wv4[k];
                         }
 #pragma unroll
                         for (int q = 0; q < QPT; q++) {
@@ -1667,6 +1717,12 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                         run1 = a1 > run1 ? a1 : run1;
                         run2 = a2 > run2 ? a2 : run2;
                         la1 = actk ? a1 : la1; la2 = actk ? a2 : la2;
+                    }
+                    if (__builtin_expect(is_sink, 0)) {
+                        const int kq = qlen - j0;
+#pragma unroll
+                        for (int k = 0; k < CPT; k++)
+                            if (kq == k) sSink[0] = wv4[k];
                     }
                     int Wl = (end_ - bal + 1 + 3) & ~3;  // (recomputed behind the barrier above so that the plane addresses are
                                                         //  not hoisted out of the row's step loop into scalar registers)
@@ -1737,6 +1793,17 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
             }
         }
         POA_MARK("row_end");
+        if (__builtin_expect(is_sink, 0) && leader) {
+            // the sink takes the first largest H[qlen] among its predecessors (rows come in the order of the sink list)
+            lead_t L = lead_load();
+            int val = POA_NEG;
+            if (qlen >= beg && qlen <= end) {
+                const int wq_ = sSink[0] >> 8;
+                val = H16 ? (wq_ <= -30000 ? POA_NEG : wq_ + base) : wq_;
+            }
+            if (!L.sink_have || val > L.sink_best) { L.sink_best = val; L.sink_row = r; L.sink_have = 1; }
+            lead_store(L);
+        }
         if (tid == 0) {
             R[r].lmax = lpos; R[r].rmax = rpos;
             if constexpr (H16) R[r].hmax = prev_hmax;
@@ -1771,21 +1838,9 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
             O.score = POA_NEG;
             O.row = 0;
         } else {
-            int bestv = INT32_MIN;
-            uint32_t brow = 0;
-            bool have = false;
-            for (uint32_t t = 0; t < pb.n_sink; t++) {
-                const uint32_t p = sink_preds[pb.sink0 + t];
-                const int bp = R[p].beg, ep = R[p].end;
-                int val = POA_NEG;
-                if (qlen >= bp && qlen <= ep) {
-                    const int Wq = (ep - (bp & ~3) + 1 + 3) & ~3;
-                    const int wv_ = hbm_word(pool + R[p].voff, Wq, qlen - (bp & ~3)) >> 8;
-                    // (16-bit storage) a sentinel stays a sentinel; a real value is made absolute
-                    val = H16 ? (wv_ <= -30000 ? POA_NEG : wv_ + R[p].base) : wv_;
-                }
-                if (!have || val > bestv) { bestv = val; brow = p; have = true; }
-            }
+            const int bestv = L.sink_best;
+            const uint32_t brow = L.sink_row;
+            const bool have = L.sink_have != 0;
             O.score = bestv;
             O.row = brow;
             O.status = (have && bestv > POA_NEG / 2) ? POA_ST_OK : POA_ST_NOALN;
@@ -1796,7 +1851,7 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
 static inline size_t poa_pk_lds_bytes(uint32_t hg_cols, uint32_t lds_cols, int nt, bool h16 = false)
 {
     const int nw = nt / 64;
-    return (h16 ? 3ull : 4ull) * hg_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw + 1 + 4 + 4) * 16 + 16;
+    return (h16 ? 3ull : 4ull) * hg_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw + 1 + 4 + 6 + 1) * 16 + 16;
 }
 
 static inline uint32_t poa_lds_cols(uint32_t max_q) { return ((max_q + 1 + 15u) & ~15u) + 16u; }
@@ -1814,6 +1869,7 @@ struct poa_prep {
     bool ok = false;
     uint32_t N = 0, qlen = 0;
     int32_t longest = 0;                // graph bases on the longest source-sink path
+    uint32_t life = 1;                  // largest dst - src over the edges: how many node-end rows a value row must outlive
     std::vector<uint4> ntab;            // node table incl. the source entry
     std::vector<uint32_t> preds, sinks; // row ids
     std::vector<uint32_t> first_row;    // per input node
@@ -1840,11 +1896,17 @@ void poa_prepare(const poa_view &v, poa_prep &g)
     g.N = (uint32_t)N;
     g.qlen = v.qlen;
     std::vector<uint32_t> in_off(nv + 1, 0), out_off(nv + 1, 0);
+    g.life = 1;
+    std::vector<uint32_t> reach(nv, 0);  // per node: how far (in nodes) its farthest successor is
     for (uint64_t e = 0; e < v.n_edges; e++) {
         if (v.esrc[e] >= v.edst[e] || v.edst[e] >= nv) return;
         in_off[v.edst[e] + 1]++;
         out_off[v.esrc[e] + 1]++;
+        reach[v.esrc[e]] = std::max(reach[v.esrc[e]], v.edst[e] - v.esrc[e]);
     }
+    // nodes whose value row is read far ahead keep it for good; the rest share a ring of POA_RING_SPAN + 1 rows
+    for (uint64_t i = 0; i < nv; i++)
+        if (reach[i] <= POA_RING_SPAN) g.life = std::max(g.life, reach[i]);
     for (uint64_t i = 0; i < nv; i++) { in_off[i + 1] += in_off[i]; out_off[i + 1] += out_off[i]; }
     std::vector<uint32_t> in_adj(v.n_edges ? v.n_edges : 1), out_adj(v.n_edges ? v.n_edges : 1), fi(nv, 0), fo(nv, 0);
     for (uint64_t e = 0; e < v.n_edges; e++) {
@@ -1875,9 +1937,13 @@ void poa_prepare(const poa_view &v, poa_prep &g)
             for (uint32_t t = in_off[i]; t < in_off[i + 1]; t++) g.preds.push_back(last_row[in_adj[t]]);
         }
         const uint32_t len = last_row[i] - g.first_row[i] + 1;
-        g.ntab[i + 1] = make_uint4(g.first_row[i], len | ((deg ? deg : 1u) << 24), (uint32_t)remain_last[i],
+        const bool is_sink = out_off[i + 1] == out_off[i];
+        // .z: remain of the node's last base; bit 31 marks a node without successors (its last row feeds the sink),
+        // bit 30 a node whose value row is read more than POA_RING_SPAN nodes ahead
+        g.ntab[i + 1] = make_uint4(g.first_row[i], len | ((deg ? deg : 1u) << 24),
+                                   (uint32_t)remain_last[i] | (is_sink ? 0x80000000u : 0u) | (reach[i] > POA_RING_SPAN ? 0x40000000u : 0u),
                                    deg <= 1 ? g.preds[pstart] : pstart);
-        if (out_off[i + 1] == out_off[i]) g.sinks.push_back(last_row[i]);
+        if (is_sink) g.sinks.push_back(last_row[i]);
     }
     g.longest = longest;
     g.ntab[0] = make_uint4(0u, 1u, (uint32_t)longest, 0u);  // the virtual source: row 0, remain = longest path
@@ -2007,7 +2073,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         parallel_for(ids.size(), [&](uint64_t t) {
             const uint32_t p = ids[t];
             poa_prepare(views[p], G[p]);
-            if (G[p].ok) { estw[p] = est_width(p); est[p] = (double)G[p].N * estw[p] * 2.2; }
+            // footprint in the pool: a direction byte per cell plus the value-row ring (packed kernel)
+            if (G[p].ok) {
+                estw[p] = est_width(p);
+                est[p] = (double)G[p].N * estw[p] * 1.15 + (double)(G[p].life + 1) * 4.0 * ((double)G[p].qlen + 8.0) + 2.0 * (double)POA_CHUNK;
+            }
             ready[p] = 1;
         });
         for (uint32_t p : ids)
@@ -2122,7 +2192,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             const poa_prep &g = G[p];
             pb.node0 = tot_nodes; pb.pred0 = tot_preds; pb.sink0 = tot_sink; pb.q0 = tot_q; pb.ops0 = tot_ops; pb.row0 = tot_rows;
             pb.seq0 = tot_seq;
-            pb.n_sink = (uint32_t)g.sinks.size(); pb.qlen = g.qlen; pb.N = g.N; pb.n_nodes = (uint32_t)g.ntab.size(); pb.pad = 0;
+            pb.n_sink = (uint32_t)g.sinks.size(); pb.qlen = g.qlen; pb.N = g.N; pb.n_nodes = (uint32_t)g.ntab.size(); pb.ring_rows = g.life + 1;
             pb.w = params->wb < 0 ? g.qlen : (uint32_t)((int64_t)params->wb + (int64_t)(params->wf * (double)g.qlen));
             tot_nodes += g.ntab.size();
             tot_preds += g.preds.size();
@@ -2420,6 +2490,13 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             for (uint64_t i = cur.i0; i < cur.i1; i++) {
                 worst = std::max(worst, (double)S.h_outs.p[i - cur.i0].maxw / estw[order[i]]);
                 mx = std::max(mx, S.h_outs.p[i - cur.i0].maxw);
+            }
+            {
+                double lsum = 0, nsum = 0;
+                uint32_t lmax = 0;
+                for (uint64_t i = cur.i0; i < cur.i1; i++) { lsum += G[order[i]].life; nsum += (double)G[order[i]].ntab.size(); lmax = std::max(lmax, G[order[i]].life); }
+                fprintf(stderr, "[vga-trace] poa:   edge span (nodes): mean %.1f, max %u; nodes per problem %.0f\n", lsum / (double)(cur.i1 - cur.i0), lmax,
+                        nsum / (double)(cur.i1 - cur.i0));
             }
             uint64_t tb = ~0ull, te = 0, tsum = 0;
             for (uint64_t i = cur.i0; i < cur.i1; i++) {
