@@ -163,7 +163,7 @@ def main():
         cpu = {"value": round(r1["aligned"] / r1["max_worker_s"], 4), "unit": "aligned reads/s", "cores": 1, "kind": "port",
                "sample": f"first {ns} reads of the workload, oracle/libvga_oracle.so (O(log n) k-mer lookup, no debug printing)",
                "seconds": round(r1["max_worker_s"], 2)}
-        ncore = max(1, min(os.cpu_count() or 1, 64))
+        ncore = max(1, min(os.cpu_count() or 1, 16))  # a GPU box gives one GPU a 16-core share
         nsa = min(len(seqs), max(ns, 4 * ncore))
         ra = run_oracle(nsa, ncore)
         cpu_all = {"value": round(ra["aligned"] / ra["wall_s"], 3), "unit": "aligned reads/s", "cores": ra["procs"], "kind": "port",
