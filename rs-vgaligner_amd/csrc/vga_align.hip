@@ -238,10 +238,15 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
             hi = std::max(hi, m->target_end[ai]);
         }
         const uint32_t ql = (uint32_t)(b->read_off[r + 1] - b->read_off[r]);
-        // footprint ~ rows x mean band width; the span on the linearised graph stands in for the rows, ~0.8 of it for the
-        // longest path (width estimate)
-        const double span = (double)(hi > lo ? hi - lo : 0) + (double)ql * 0.25;
-        proxy[p] = span * (650.0 + 0.3 * std::max(0.0, 0.8 * span - (double)ql));
+        // footprint ~ rows x mean band width.  Rows: the chain's span on the linearised graph plus what the extension
+        // adds for the part of the read the chain does not cover (it walks every allele, ~1.6 graph bases per read
+        // base on DRB1-3123); the longest path is ~0.85 of the rows (width estimate).
+        const uint64_t c0 = m->chain_anchor_off[c], c1 = m->chain_anchor_off[c + 1];
+        const double q_first = c1 > c0 ? (double)m->query_begin[a0 + m->chain_anchor_idx[c0]] : 0.0;
+        const double q_last = c1 > c0 ? (double)m->query_begin[a0 + m->chain_anchor_idx[c1 - 1]] + (double)k : (double)ql;
+        const double uncovered = q_first + std::max(0.0, (double)ql - q_last);
+        const double rows = (double)(hi > lo ? hi - lo : 0) + 1.6 * uncovered;
+        proxy[p] = rows * (650.0 + 0.3 * std::max(0.0, 0.85 * rows - (double)ql));
         feed.views[p] = {nullptr, nullptr, 0, nullptr, nullptr, 0, b->reads.data() + b->read_off[r], ql};
     });
     feed.proxy = proxy.data();

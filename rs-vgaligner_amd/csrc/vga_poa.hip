@@ -2495,8 +2495,15 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 double lsum = 0, nsum = 0;
                 uint32_t lmax = 0;
                 for (uint64_t i = cur.i0; i < cur.i1; i++) { lsum += G[order[i]].life; nsum += (double)G[order[i]].ntab.size(); lmax = std::max(lmax, G[order[i]].life); }
-                fprintf(stderr, "[vga-trace] poa:   edge span (nodes): mean %.1f, max %u; nodes per problem %.0f\n", lsum / (double)(cur.i1 - cur.i0), lmax,
-                        nsum / (double)(cur.i1 - cur.i0));
+                double csum = 0, vsum = 0, rsum = 0, esum = 0;
+                for (uint64_t i = cur.i0; i < cur.i1; i++) {
+                    csum += (double)S.h_outs.p[i - cur.i0].cells; vsum += (double)S.h_outs.p[i - cur.i0].vcells; rsum += G[order[i]].N;
+                    esum += est[order[i]];
+                }
+                const double nbd = (double)(cur.i1 - cur.i0);
+                fprintf(stderr, "[vga-trace] poa:   edge span (nodes): mean %.1f, max %u; nodes %.0f; rows %.0f, cells %.1f M, value cells %.1f M, "
+                                "estimate %.1f MB per problem, pool scale %.2f\n", lsum / nbd, lmax, nsum / nbd, rsum / nbd, csum / nbd / 1e6,
+                        vsum / nbd / 1e6, esum / nbd / 1e6, W.pool_scale);
             }
             uint64_t tb = ~0ull, te = 0, tsum = 0;
             for (uint64_t i = cur.i0; i < cur.i1; i++) {
@@ -2532,6 +2539,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 all_rows += G[order[i]].N; all_q += G[order[i]].qlen;
             }
         }
+    }
+    if (tr.on && feed.proxy) {
+        for (uint64_t i = 0; i < order.size() && i < n; i += std::max<uint64_t>(1, n / 12))
+            fprintf(stderr, "[vga-trace] poa:   launch position %llu: proxy %.3g, rows %u, longest path %d, query %u, estimate %.1f MB\n",
+                    (unsigned long long)i, feed.proxy[order[i]], G[order[i]].N, G[order[i]].longest, G[order[i]].qlen, est[order[i]] / 1e6);
     }
     // drain both streams (also on the error paths: the slots belong to the context)
     for (int i = 1; i < n_slots; i++) (void)hipStreamSynchronize(sarr[i]);
