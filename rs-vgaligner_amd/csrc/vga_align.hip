@@ -14,6 +14,7 @@
 #include "vga_poa_internal.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 
@@ -100,30 +101,43 @@ struct scratch_t {
     std::vector<uint32_t> best;      // per packed handle: largest remaining budget seen
     std::vector<handle_t> touched;
     std::vector<std::pair<uint32_t, handle_t>> cur, next;
-    std::vector<handle_t> nb;
+    std::vector<handle_t> nb, lo, hi;
 };
 
 // one direction of src/align.rs:551-591 / 616-656.  The reference's walk keeps no visited set (its
 // frontier grows exponentially on bubble chains); a handle ends up in the range iff it is reachable
-// with a positive remaining budget, which is what the per-handle best-budget relaxation computes.
+// with a positive remaining budget, which is what the per-handle best-budget relaxation computes (a handle is
+// re-expanded only when it is reached with a larger budget than before).
 void extend_dir(const index_view &iv, handle_t from, uint32_t diff, bool incoming, std::vector<handle_t> &hs, scratch_t &sc)
 {
+    const vga_dev_index &ix = iv.ix;
+    // neighbours of a handle in walk direction, straight from the edge lists when the handle is forward (it always is
+    // with only_forward; the general accessor covers the rest)
+    auto for_each_nb = [&](handle_t h, auto &&f) {
+        if (!(h & 1)) {
+            const uint32_t pos = (h >> 1) - 1;
+            const uint32_t s = incoming ? ix.edge_idx[pos] : ix.edge_idx[pos] + ix.edges_to[pos];
+            const uint32_t e = incoming ? ix.edge_idx[pos] + ix.edges_to[pos] : ix.edge_idx[pos + 1];
+            for (uint32_t i = s; i < e; i++) f(ix.edges[i]);
+        } else {
+            if (incoming) iv.incoming(h, sc.nb); else iv.outgoing(h, sc.nb);
+            for (handle_t x : sc.nb) f(x);
+        }
+    };
     sc.cur.clear();
-    if (incoming) iv.incoming(from, sc.nb); else iv.outgoing(from, sc.nb);
-    for (handle_t h : sc.nb) sc.cur.emplace_back(diff, h);
+    for_each_nb(from, [&](handle_t x) { sc.cur.emplace_back(diff, x); });
     while (!sc.cur.empty()) {
         sc.next.clear();
         for (auto &it : sc.cur) {
-            uint32_t left = it.first;
-            handle_t h = it.second;
+            const uint32_t left = it.first;
+            const handle_t h = it.second;
             if (sc.best[h] >= left) continue;
             if (sc.best[h] == 0) { hs.push_back(h); sc.touched.push_back(h); }
             sc.best[h] = left;
-            uint32_t len = iv.node_len(h);
+            const uint32_t len = iv.node_len(h);
             if (len < left) {
-                uint32_t rem = left - len;
-                if (incoming) iv.incoming(h, sc.nb); else iv.outgoing(h, sc.nb);
-                for (handle_t x : sc.nb) sc.next.emplace_back(rem, x);
+                const uint32_t rem = left - len;
+                for_each_nb(h, [&](handle_t x) { if (sc.best[x] < rem) sc.next.emplace_back(rem, x); });
             }
         }
         sc.cur.swap(sc.next);
@@ -133,22 +147,28 @@ void extend_dir(const index_view &iv, handle_t from, uint32_t diff, bool incomin
 }
 
 // find_range_chain + extend_range_chain_2 + find_nodes_edges_for_abpoa for one chain
+static std::atomic<long long> g_ns_range{0}, g_ns_extend{0}, g_ns_seq{0}, g_ns_edges{0};  // VGA_TRACE: where the time goes
 void build_subgraph(const index_view &iv, const vga_map_result *m, uint64_t read, uint64_t chain, uint32_t k, uint32_t qlen,
                     subgraph_t &sg, scratch_t &sc)
 {
+    auto tnow = []() { return std::chrono::steady_clock::now(); };
+    auto t_a = tnow();
     const uint64_t a0 = m->anchor_off[read];
     const uint64_t c0 = m->chain_anchor_off[chain], c1 = m->chain_anchor_off[chain + 1];
-    handle_t min_h = 0xFFFFFFFFu, max_h = 0;
+    // smallest / largest handle over the anchors' begin and inclusive end positions (align.rs:286-308).  The position ->
+    // handle map is monotonic, so it is enough to look the extreme positions up.
+    uint32_t pmin = 0xFFFFFFFFu, pmax = 0;
     for (uint64_t t = c0; t < c1; t++) {
         const uint64_t ai = a0 + m->chain_anchor_idx[t];
-        handle_t s = iv.handle_from_fwd_pos(m->target_begin[ai]);
-        handle_t e = iv.handle_from_fwd_pos(m->target_end[ai] - 1);  // get_end_seqpos_inclusive, chain.rs:65-70
-        min_h = std::min(min_h, std::min(s, e));
-        max_h = std::max(max_h, std::max(s, e));
+        const uint32_t s = m->target_begin[ai], e = m->target_end[ai] - 1;  // get_end_seqpos_inclusive, chain.rs:65-70
+        pmin = std::min(pmin, std::min(s, e));
+        pmax = std::max(pmax, std::max(s, e));
     }
+    const handle_t min_h = iv.handle_from_fwd_pos(pmin), max_h = iv.handle_from_fwd_pos(pmax);
     sg.handles.clear();
     for (uint32_t x = min_h >> 1; x <= (max_h >> 1); x++) sg.handles.push_back(x * 2);  // align.rs:358-364
     const handle_t first_handle = sg.handles.front(), last_handle = sg.handles.back();
+    auto t_b = tnow();
     const uint64_t fa = a0 + m->chain_anchor_idx[c0], la = a0 + m->chain_anchor_idx[c1 - 1];
     // align.rs:536-547
     uint32_t prefix_diff = m->query_begin[fa];
@@ -160,23 +180,57 @@ void build_subgraph(const index_view &iv, const vga_map_result *m, uint64_t read
     uint32_t end_suffix_on_node = iv.select((last_handle >> 1) + 1) - 1 - (m->target_end[la] - 1);
     if (end_suffix_on_node > suffix_diff) suffix_diff = 0; else suffix_diff -= end_suffix_on_node;
     if (suffix_diff > 0) extend_dir(iv, last_handle, suffix_diff, false, sg.handles, sc);
-    std::sort(sg.handles.begin(), sg.handles.end());
-    sg.handles.erase(std::unique(sg.handles.begin(), sg.handles.end()), sg.handles.end());
+    // sort + dedup (align.rs:658-659).  The id range is sorted already and the walks only add forward handles, so the
+    // result is  sorted(added below the range) + range + sorted(added above it);  anything else takes the general route.
+    {
+        const size_t n_range = (size_t)((last_handle - first_handle) / 2 + 1);
+        bool simple = true;
+        sc.lo.clear();
+        sc.hi.clear();
+        for (size_t i = n_range; i < sg.handles.size(); i++) {
+            const handle_t h = sg.handles[i];
+            if (h < first_handle) sc.lo.push_back(h);
+            else if (h > last_handle) sc.hi.push_back(h);
+            else if (h & 1) simple = false;  // a reverse handle inside the range (not reachable with only_forward)
+        }
+        if (simple) {
+            std::sort(sc.lo.begin(), sc.lo.end());
+            sc.lo.erase(std::unique(sc.lo.begin(), sc.lo.end()), sc.lo.end());
+            std::sort(sc.hi.begin(), sc.hi.end());
+            sc.hi.erase(std::unique(sc.hi.begin(), sc.hi.end()), sc.hi.end());
+            sg.handles.resize(n_range);
+            sg.handles.insert(sg.handles.begin(), sc.lo.begin(), sc.lo.end());
+            sg.handles.insert(sg.handles.end(), sc.hi.begin(), sc.hi.end());
+        } else {
+            std::sort(sg.handles.begin(), sg.handles.end());
+            sg.handles.erase(std::unique(sg.handles.begin(), sg.handles.end()), sg.handles.end());
+        }
+    }
+    auto t_c = tnow();
     // align.rs:670-724
     sg.seqs.clear();
     sg.node_off.assign(1, 0);
     for (handle_t h : sg.handles) { iv.append_seq(h, sg.seqs); sg.node_off.push_back(sg.seqs.size()); }
+    auto t_d = tnow();
     sg.esrc.clear();
     sg.edst.clear();
+    // position of a handle in the sorted list: a dense map over the handles (sc.best is free between extensions),
+    // stored as position + 1
+    for (uint32_t i = 0; i < sg.handles.size(); i++) sc.best[sg.handles[i]] = i + 1;
     for (uint32_t i = 0; i < sg.handles.size(); i++) {
         iv.outgoing(sg.handles[i], sc.nb);
         for (handle_t t : sc.nb) {
-            auto it = std::lower_bound(sg.handles.begin(), sg.handles.end(), t);
-            if (it == sg.handles.end() || *it != t) continue;
-            uint32_t e = (uint32_t)(it - sg.handles.begin());
-            if (i < e) { sg.esrc.push_back(i); sg.edst.push_back(e); }  // RangeOrient::Forward, align.rs:718
+            const uint32_t e1 = sc.best[t];
+            if (e1 == 0) continue;  // the neighbour is not in the range
+            if (i < e1 - 1) { sg.esrc.push_back(i); sg.edst.push_back(e1 - 1); }  // RangeOrient::Forward, align.rs:718
         }
     }
+    for (handle_t h : sg.handles) sc.best[h] = 0;
+    auto t_e = tnow();
+    g_ns_range += std::chrono::duration_cast<std::chrono::nanoseconds>(t_b - t_a).count();
+    g_ns_extend += std::chrono::duration_cast<std::chrono::nanoseconds>(t_c - t_b).count();
+    g_ns_seq += std::chrono::duration_cast<std::chrono::nanoseconds>(t_d - t_c).count();
+    g_ns_edges += std::chrono::duration_cast<std::chrono::nanoseconds>(t_e - t_d).count();
 }
 
 template <typename T>
@@ -355,6 +409,10 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
     res->ms_traceback = tm.ms_tb;
     res->ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     tr.mark("assemble records");
+    if (tr.on) {
+        fprintf(stderr, "[vga-trace] align: subgraph thread time: range %.1f ms, extension %.1f ms, node strings %.1f ms, edges %.1f ms\n",
+                g_ns_range.exchange(0) / 1e6, g_ns_extend.exchange(0) / 1e6, g_ns_seq.exchange(0) / 1e6, g_ns_edges.exchange(0) / 1e6);
+    }
     *out = res;
     return VGA_OK;
 }
