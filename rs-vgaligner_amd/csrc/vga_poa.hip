@@ -2035,9 +2035,13 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         int g1b = 0, g2b = 0;
         while ((1 << g1b) <= params->gap_open1 + params->gap_ext1) g1b++;
         while ((1 << g2b) <= params->gap_open2 + params->gap_ext2) g2b++;
-        const size_t need = g1b + g2b <= 8 ? poa_pk_lds_bytes(lds_cols_all, lds_cols_all, 128) : poa_lds_bytes(lds_cols_all, 128);
+        const char *force = getenv("VGA_POA_KERNEL");
+        const bool unpacked = g1b + g2b > 8 || (force && strstr(force, "unpacked"));
+        // the packed kernel keeps a 4096-column window of the row state; the unpacked one every column
+        const uint32_t hg_need = std::min<uint32_t>(lds_cols_all, 4096);
+        const size_t need = unpacked ? poa_lds_bytes(lds_cols_all, 128) : poa_pk_lds_bytes(hg_need, lds_cols_all, 128);
         if (need > 160 * 1024 - 256)
-            return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query of %u bases does not fit the LDS-resident POA kernel (limit ~35 kbp, ~22 kbp with large gap penalties)", max_q);
+            return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query of %u bases does not fit the LDS-resident POA kernel (limit ~280 kbp, ~22 kbp with large gap penalties)", max_q);
     }
 
     // ---- launch order and lazy preparation.  The caller may hand the problems over lazily (feed.prepare fills the graph

@@ -236,6 +236,11 @@ def test_map_without_dp_arrays_feeds_the_same_alignments(oracle, ctx, drb1):
     assert a1.cigar == a2.cigar and a1.cs == a2.cs and a1.path_handles.tolist() == a2.path_handles.tolist()
 
 
+# the diagnostic VGA_POA_KERNEL=unpacked build of the DP keeps whole rows in LDS: long queries are refused there
+_long_ok = pytest.mark.skipif("unpacked" in os.environ.get("VGA_POA_KERNEL", ""), reason="forced unpacked kernel: ~22 kbp limit")
+
+
+@_long_ok
 def test_poa_16bit_row_state_experimental(oracle, ctx, drb1, monkeypatch):
     """VGA_POA_H16=1: int16 row state relative to a per-row base, packed two-cells-per-instruction interior path.
     Same results as the oracle; a problem whose scores come near the int16 range is re-run with 32-bit words
@@ -280,3 +285,17 @@ def test_unsupported_inputs_fail_loudly(oracle, ctx, drb1):
         ctx.batch(["ACGT" * 10]).map(mp)
     with pytest.raises(p.VgaError):  # edge with src >= dst
         ctx.poa_batch([(["AC", "GT"], [(1, 0)], "ACGT")])
+    # a query whose column codes no longer fit the LDS next to the row window
+    with pytest.raises(p.VgaError) as e:
+        ctx.poa_batch([(["ACGT"], [], "A" * 400000)])
+    assert e.value.code == -4
+
+
+@_long_ok
+def test_poa_long_query_beyond_the_lds_window(oracle, ctx):
+    """60 kbp query: 15x the 4096-column LDS window, band 2 x 610 + 1 (banded), tiny graph + a longer one"""
+    rng = random.Random(5)
+    q = "".join(rng.choice("ACGT") for _ in range(60000))
+    g = [q[i:i + 500] for i in range(0, 3000, 500)]
+    _check_poa(oracle, ctx, [(g, [(i, i + 1) for i in range(len(g) - 1)], q[:3000] + q[40000:40500]),
+                             (["ACGT", "TTGA"], [(0, 1)], q)])
