@@ -87,6 +87,8 @@ typedef struct vga_batch vga_batch;
  * (n_reads+1 offsets).  Copies the reads to HBM (the Vec<QuerySequence> of src/io.rs:74-162). */
 int vga_batch_create(vga_ctx *ctx, const char *reads_concat, const uint64_t *read_off, uint64_t n_reads,
                      vga_batch **out);
+/* May be called before or after vga_ctx_destroy of the batch's context: destroying the context releases the
+ * batch's device memory and detaches it (later map / align calls on it return VGA_ERR_ARG). */
 void vga_batch_destroy(vga_batch *b);
 
 /* ---- map: anchors + chains ------------------------------------------------------------------ */

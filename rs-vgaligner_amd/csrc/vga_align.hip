@@ -253,7 +253,7 @@ extern "C" void vga_align_result_free(vga_align_result *r)
 extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t align_best_n, const vga_poa_params *params,
                                vga_align_result **out)
 {
-    if (!b || !m || !params || !out) return VGA_ERR_ARG;
+    if (!b || !m || !params || !out || !b->ctx) return VGA_ERR_ARG;  // b->ctx == nullptr: the context was destroyed
     vga_ctx *ctx = b->ctx;
     *out = nullptr;
     if (!ctx->index.loaded) return vga_set_error(ctx, VGA_ERR_NO_INDEX, "vga_align_batch: no index uploaded");

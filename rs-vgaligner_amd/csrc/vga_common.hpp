@@ -69,10 +69,14 @@ struct vga_ctx {
     void (*map_ws_free)(void *) = nullptr;
     void *poa_ws = nullptr;
     void (*poa_ws_free)(void *) = nullptr;
+    // live read batches: vga_ctx_destroy releases their device memory and detaches them, so a batch handle may be
+    // destroyed after its context
+    std::vector<struct vga_batch *> batches;
 };
 
 struct vga_batch {
-    vga_ctx *ctx = nullptr;
+    vga_ctx *ctx = nullptr;  // nullptr once the context is gone (map / align calls then fail with VGA_ERR_ARG)
+    int device = 0;
     uint64_t n_reads = 0;
     uint64_t total_bases = 0;
     std::vector<uint64_t> read_off;  // host copy

@@ -78,6 +78,13 @@ extern "C" void vga_ctx_destroy(vga_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (vga_batch *b : ctx->batches) {
+        if (b->d_reads) (void)hipFree(b->d_reads);
+        if (b->d_read_off) (void)hipFree(b->d_read_off);
+        b->d_reads = nullptr;
+        b->d_read_off = nullptr;
+        b->ctx = nullptr;
+    }
     if (ctx->map_ws && ctx->map_ws_free) ctx->map_ws_free(ctx->map_ws);
     if (ctx->poa_ws && ctx->poa_ws_free) ctx->poa_ws_free(ctx->poa_ws);
     vga_index_release(ctx->index);
@@ -301,6 +308,7 @@ extern "C" int vga_batch_create(vga_ctx *ctx, const char *reads_concat, const ui
         if (read_off[i + 1] < read_off[i]) return vga_set_error(ctx, VGA_ERR_ARG, "read_off not monotone at %llu", (unsigned long long)i);
     vga_batch *b = new vga_batch();
     b->ctx = ctx;
+    b->device = ctx->device;
     b->n_reads = n_reads;
     b->total_bases = n_reads ? read_off[n_reads] - read_off[0] : 0;
     b->read_off.resize(n_reads + 1);
@@ -314,6 +322,7 @@ extern "C" int vga_batch_create(vga_ctx *ctx, const char *reads_concat, const ui
     if (e == hipSuccess)
         e = hipMemcpyAsync(b->d_read_off, b->read_off.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    ctx->batches.push_back(b);
     if (e != hipSuccess) {
         vga_batch_destroy(b);
         return vga_set_error(ctx, VGA_ERR_HIP, "vga_batch_create: %s", hipGetErrorString(e));
@@ -325,7 +334,11 @@ extern "C" int vga_batch_create(vga_ctx *ctx, const char *reads_concat, const ui
 extern "C" void vga_batch_destroy(vga_batch *b)
 {
     if (!b) return;
-    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    if (b->ctx) {
+        auto &v = b->ctx->batches;
+        v.erase(std::remove(v.begin(), v.end(), b), v.end());
+        (void)hipSetDevice(b->device);
+    }
     if (b->d_reads) (void)hipFree(b->d_reads);
     if (b->d_read_off) (void)hipFree(b->d_read_off);
     delete b;

@@ -377,7 +377,7 @@ extern "C" void vga_map_result_free(vga_map_result *r)
 
 extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map_result **out)
 {
-    if (!b || !params || !out) return VGA_ERR_ARG;
+    if (!b || !params || !out || !b->ctx) return VGA_ERR_ARG;  // b->ctx == nullptr: the context was destroyed
     vga_ctx *ctx = b->ctx;
     *out = nullptr;
     (void)hipSetDevice(ctx->device);

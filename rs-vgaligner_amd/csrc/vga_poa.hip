@@ -2292,6 +2292,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             if (tr.on)
                 fprintf(stderr, "[vga-trace] poa: launch %u problems, NT %d, %s, window %u of %u columns, widest estimate %.0f, LDS %zu B\n",
                         nb, nt, h16 ? "16-bit rows" : "32-bit rows", hg_cols, lds_cols, mw, lds);
+            (void)hipGetLastError();  // a launch failure below must be this launch's, not an older ignored status
 #define POA_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_sink.p, P, S.d_rows.p, pool_base,          \
                  W.d_next.p + slot, half_pool, S.d_outs.p, lds_cols
 #define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, g1bits

@@ -136,3 +136,114 @@ def write_fasta(reads: List[SimRead], path: str) -> None:
     with open(path, "w") as f:
         for r in reads:
             f.write(f">{r.name}\n{r.seq}\n")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# graphs of BASELINE.json configs #4 and #5
+
+# The HLA-zoo loci whose shipped graph.gfa is forward-only, acyclic and already numbered in topological order (the
+# reference requires `odgi sort`-ed input and odgi is not available offline; the other 11 loci contain reverse links,
+# back edges or self loops as shipped).  Config #4 = the disjoint union of these nine.
+HLA_FORWARD_ACYCLIC = ["hla/1-simple", "DRB1-3123", "hla/6-DRB5-3127", "hla/11-C-3107-spoa", "hla/12-DMA-3108-spoa",
+                       "hla/13-V-352962-spoa", "hla/14-DOB-3112-spoa", "hla/18-B-3106-smooth", "hla/19-MICB-4227-smooth"]
+
+
+def config4_graph(data_dir: str, out_path: str) -> Tuple[int, int, int]:
+    """the merged HLA graph of config #4 from the graph files under tests/golden/data"""
+    import os
+
+    return merge_gfas([os.path.join(data_dir, n + ".gfa") for n in HLA_FORWARD_ACYCLIC], out_path)
+
+
+def merge_gfas(gfa_paths: List[str], out_path: str) -> Tuple[int, int, int]:
+    """Disjoint union of GFA graphs with cumulative id offsets (ids stay contiguous and topological when every input's
+    are).  Path names get the input's ordinal as a prefix.  Returns (nodes, edges, bases)."""
+    off = 0
+    n_edges = n_bases = 0
+    with open(out_path, "w") as out:
+        out.write("H\tVN:Z:1.0\n")
+        for gi, gp in enumerate(gfa_paths):
+            top = 0
+            with open(gp) as f:
+                for ln in f:
+                    p = ln.rstrip("\n").split("\t")
+                    if p[0] == "S":
+                        top = max(top, int(p[1]))
+                        n_bases += len(p[2])
+                        out.write("S\t%d\t%s\n" % (int(p[1]) + off, p[2]))
+                    elif p[0] == "L":
+                        n_edges += 1
+                        out.write("L\t%d\t%s\t%d\t%s\t%s\n" % (int(p[1]) + off, p[2], int(p[3]) + off, p[4], p[5] if len(p) > 5 else "0M"))
+                    elif p[0] == "P":
+                        steps = ",".join("%d%s" % (int(s[:-1]) + off, s[-1]) for s in p[2].split(",") if s)
+                        out.write("P\tg%d_%s\t%s\t*\n" % (gi, p[1], steps))
+            off += top
+    return off, n_edges, n_bases
+
+
+def synth_pangenome(out_path: str, total_bp: int = 1_000_000, seed: int = 77, n_haps: int = 16, mean_node: int = 32,
+                    snp_every: int = 100, indel_every: int = 1000) -> Tuple[int, int, int]:
+    """Config #5: a random backbone (uniform ACGT) cut into nodes of mean `mean_node` bp (geometric), a SNP bubble
+    about every `snp_every` bp and a 1-20 bp indel bubble about every `indel_every` bp; ids are assigned in
+    topological order (what `odgi sort -p Ygs` would produce); `n_haps` haplotype paths pick bubble arms at random.
+    Returns (nodes, edges, bases)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    segs: List[bytes] = []
+    edges: List[Tuple[int, int]] = []
+    # per backbone step: ("n", id) plain node, ("s", ref, alt) SNP arms, ("i", id) optional indel node
+    plan: List[Tuple] = []
+    made = 0
+    p_snp = mean_node / snp_every
+    p_indel = mean_node / indel_every
+
+    def new_node(n):
+        segs.append(acgt[rng.integers(0, 4, size=n)].tobytes())
+        return len(segs)  # 1-based id
+
+    prev: List[int] = []
+    skip_from: List[int] = []  # nodes that may also jump over the next (optional) node
+    while made < total_bp:
+        n = int(rng.geometric(1.0 / mean_node))
+        a = new_node(n)
+        made += n
+        for pnode in prev + skip_from:
+            edges.append((pnode, a))
+        plan.append(("n", a))
+        prev, skip_from = [a], []
+        u = rng.random()
+        if made >= total_bp:
+            break
+        if u < p_snp:
+            ref = new_node(1)
+            b = int(rng.integers(1, 4))
+            alt_base = acgt[(int(np.searchsorted(acgt, segs[ref - 1][0])) + b) & 3]
+            segs.append(bytes([alt_base]))
+            alt = len(segs)
+            edges += [(a, ref), (a, alt)]
+            plan.append(("s", ref, alt))
+            prev = [ref, alt]
+            made += 1
+        elif u < p_snp + p_indel:
+            ins = new_node(int(rng.integers(1, 21)))
+            edges.append((a, ins))
+            plan.append(("i", ins))
+            prev, skip_from = [ins], [a]
+            made += len(segs[ins - 1])
+    with open(out_path, "w") as out:
+        out.write("H\tVN:Z:1.0\n")
+        for i, s in enumerate(segs):
+            out.write("S\t%d\t%s\n" % (i + 1, s.decode()))
+        for a, b in sorted(edges):
+            out.write("L\t%d\t+\t%d\t+\t0M\n" % (a, b))
+        for h in range(n_haps):
+            steps = []
+            for st in plan:
+                if st[0] == "n":
+                    steps.append(st[1])
+                elif st[0] == "s":
+                    steps.append(st[1] if rng.random() < 0.5 else st[2])
+                elif rng.random() < 0.5:
+                    steps.append(st[1])
+            out.write("P\thap%d\t%s\t*\n" % (h, ",".join("%d+" % s for s in steps)))
+    return len(segs), len(edges), sum(len(s) for s in segs)

@@ -26,3 +26,23 @@ def oracle():
 @pytest.fixture(scope="session")
 def data_dir():
     return DATA
+
+
+@pytest.fixture(scope="session")
+def config4_gfa(tmp_path_factory):
+    """BASELINE config #4 graph: disjoint union of the nine forward-acyclic HLA-zoo loci (readsim.HLA_FORWARD_ACYCLIC)"""
+    import __graft_entry__ as ge
+
+    out = str(tmp_path_factory.mktemp("cfg4") / "hla9.gfa")
+    assert ge.load_package().readsim.config4_graph(DATA, out) == (7122, 9530, 70337)
+    return out
+
+
+@pytest.fixture(scope="session")
+def config5_small_gfa(tmp_path_factory):
+    """BASELINE config #5 generator at 60 kbp (the oracle's size); the full 1 Mbp graph is built in test_gpu_fullsize"""
+    import __graft_entry__ as ge
+
+    out = str(tmp_path_factory.mktemp("cfg5") / "syn60k.gfa")
+    ge.load_package().readsim.synth_pangenome(out, 60000, seed=78)
+    return out

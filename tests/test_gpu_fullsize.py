@@ -145,6 +145,53 @@ def test_config3_full_length_alignments_are_self_consistent(env):
     assert al2.cigar == al.cigar and al2.cs == al.cs and np.array_equal(al2.path_handles, al.path_handles)
 
 
+def _run_and_replay(gfa, n_reads, min_aligned):
+    p = pkg()
+    hi = p.HostIndex.build_from_gfa(gfa, 11)
+    ctx = p.Context(0)
+    try:
+        hi.upload(ctx)
+        arr = hi.arrays()
+        reads = p.readsim.config3_reads(gfa, n_reads)
+        seqs = [r.seq for r in reads]
+        b = ctx.batch(seqs)
+        mo = b.map()
+        al = b.align(mo)
+        assert int(al.aligned.sum()) >= min_aligned
+        edges_of = _edges_of(arr)
+        for r in range(len(seqs)):
+            if al.aligned[r]:
+                _check_alignment(seqs[r], al, r, arr, edges_of)
+        return mo, al, reads
+    finally:
+        ctx.close()
+
+
+def test_config4_merged_hla_alignments_are_self_consistent(config4_gfa):
+    """config #4 shape: the merged HLA graph (nine loci), ONT-profile reads of 10 kbp or the full path where shorter"""
+    mo, al, reads = _run_and_replay(config4_gfa, 256, 250)
+    # an alignment never spans two loci (the union is disjoint); it need not be the locus the read was drawn from --
+    # DRB1 reads can chain better on the paralogous one-node DRB5 graph
+    bounds = np.cumsum([0, 19, 4792, 1, 601, 173, 80, 209, 494, 753])
+    home = 0
+    for r in range(len(reads)):
+        if al.aligned[r]:
+            ids = al.path_handles[int(al.path_off[r]):int(al.path_off[r + 1])] >> 1
+            g = int(np.searchsorted(bounds, int(ids.min()), side="left")) - 1
+            assert bounds[g] < int(ids.min()) and int(ids.max()) <= bounds[g + 1], f"read {r} crosses loci"
+            home += g == int(reads[r].path.split("_")[0][1:])
+    assert home >= 0.8 * len(reads)
+
+
+def test_config5_one_mbp_synthetic_pangenome(tmp_path):
+    """config #5 shape: 1 Mbp synthetic pangenome (50 835 nodes, k=11 index of 1.7 M k-mers / 4.0 M positions: every
+    query k-mer also hits ~0.25 random places), 10 kbp ONT-profile reads"""
+    gfa = str(tmp_path / "syn1m.gfa")
+    assert pkg().readsim.synth_pangenome(gfa) == (50835, 61514, 1009742)
+    mo, al, reads = _run_and_replay(gfa, 160, 158)
+    assert mo.n_anchors / len(reads) > 6000  # true + random hits
+
+
 def test_host_map_reads_writes_reference_style_gaf(env, tmp_path):
     """the C++ map_reads (src/map.rs:27-216): file naming and record shape, on a small real run"""
     p, hi, ctx, arr = env

@@ -219,6 +219,29 @@ def test_align_config3_sample(oracle, ctx, drb1):
     _check_align(oracle, ctx, ix, pkg().readsim.config3_reads(DRB1, 3))
 
 
+def test_align_config4_merged_hla_sample(oracle, ctx, config4_gfa):
+    """BASELINE config #4 (sample): reads from several loci of the merged HLA graph, full path length where the
+    locus is shorter than 10 kbp; includes the one-node DRB5 locus (12.9 kbp in a single node)"""
+    ix = oracle.Index(oracle.Graph.from_gfa(config4_gfa), 11)
+    upload_oracle_index(ctx, ix)
+    reads = pkg().readsim.config3_reads(config4_gfa, 24)
+    seen, pick = set(), []
+    for r in reads:  # one read per locus present in the draw
+        if r.path.split("_")[0] not in seen:
+            seen.add(r.path.split("_")[0])
+            pick.append(r)
+    assert len(pick) >= 5
+    _check_align(oracle, ctx, ix, pick)
+
+
+def test_align_config5_synthetic_pangenome_sample(oracle, ctx, config5_small_gfa):
+    """BASELINE config #5 generator (SNP bubble / 100 bp, indel bubble / 1 kbp, 32 bp nodes) at 60 kbp"""
+    ix = oracle.Index(oracle.Graph.from_gfa(config5_small_gfa), 11)
+    upload_oracle_index(ctx, ix)
+    _check_align(oracle, ctx, ix, pkg().readsim.config3_reads(config5_small_gfa, 6))
+    _check_align(oracle, ctx, ix, pkg().readsim.config2_reads(config5_small_gfa, 40))
+
+
 def test_map_without_dp_arrays_feeds_the_same_alignments(oracle, ctx, drb1):
     """vga_map_params.emit_dp = 0: ids / f(i) / predecessors stay on the GPU, chains and alignments are unchanged"""
     _, ix = drb1
@@ -299,3 +322,26 @@ def test_poa_long_query_beyond_the_lds_window(oracle, ctx):
     g = [q[i:i + 500] for i in range(0, 3000, 500)]
     _check_poa(oracle, ctx, [(g, [(i, i + 1) for i in range(len(g) - 1)], q[:3000] + q[40000:40500]),
                              (["ACGT", "TTGA"], [(0, 1)], q)])
+
+
+def test_batch_outlives_its_context(drb1, oracle):
+    """a vga_batch handle destroyed after vga_ctx_destroy (the order a garbage collector picks) must not touch the
+    freed context, and must not disturb the next context of the process"""
+    p = pkg()
+    _, ix = drb1
+    seqs = [r.seq for r in p.readsim.config2_reads(DRB1, 8)]
+    c1 = p.Context(0)
+    upload_oracle_index(c1, ix)
+    b1 = c1.batch(seqs)
+    n1 = int(b1.align(b1.map()).aligned.sum())
+    c1.close()
+    with pytest.raises(p.VgaError) as e:
+        b1.map()
+    assert e.value.code == -1  # VGA_ERR_ARG: detached batch
+    b1.close()
+    c2 = p.Context(0)
+    upload_oracle_index(c2, ix)
+    b2 = c2.batch(seqs)
+    assert int(b2.align(b2.map()).aligned.sum()) == n1
+    b2.close()
+    c2.close()

@@ -22,6 +22,44 @@ def test_host_index_equals_oracle_index(oracle, gfa, k):
         assert np.array_equal(got["kmer_pos_table"][f], want["kmer_pos_table"][f]), f
 
 
+def _same_index(oracle, path, k):
+    got = pkg().HostIndex.build_from_gfa(path, k).arrays()
+    want = oracle_index_arrays(oracle.Index(oracle.Graph.from_gfa(path), k))
+    assert got["k"] == want["k"] and got["seq_fwd"] == want["seq_fwd"] and got["kmer_keys"] == want["kmer_keys"]
+    for key in ("node_seq_idx", "node_edge_idx", "node_edges_to", "edges", "kmer_starts"):
+        assert np.array_equal(got[key], np.asarray(want[key], dtype=np.uint64)), key
+    for f in ("start", "end", "start_orient", "end_orient"):
+        assert np.array_equal(got["kmer_pos_table"][f], want["kmer_pos_table"][f]), f
+
+
+def test_host_index_equals_oracle_index_config4_and_config5_graphs(oracle, config4_gfa, config5_small_gfa):
+    """the merged HLA graph (config #4) and the synthetic pangenome generator (config #5, at 60 kbp)"""
+    _same_index(oracle, config4_gfa, 11)
+    _same_index(oracle, config5_small_gfa, 11)
+
+
+def test_graph_generators_are_deterministic_and_topological(tmp_path, config4_gfa):
+    rs = pkg().readsim
+    a, b = str(tmp_path / "a.gfa"), str(tmp_path / "b.gfa")
+    na = rs.synth_pangenome(a, 20000, seed=5)
+    assert na == rs.synth_pangenome(b, 20000, seed=5) and open(a).read() == open(b).read()
+    for path in (a, config4_gfa):
+        segs, paths = rs.parse_gfa_paths(path)
+        assert sorted(segs) == list(range(1, len(segs) + 1))
+        edges = set()
+        for ln in open(path):
+            if ln.startswith("L\t"):
+                f = ln.split("\t")
+                assert f[2] == "+" and f[4] == "+" and int(f[1]) < int(f[3])
+                edges.add((int(f[1]), int(f[3])))
+        for name, steps in paths:
+            if any(rev for _, rev in steps):
+                continue  # HLA paths stored on the reverse strand: skipped by the read sampler
+            assert all((x[0], y[0]) in edges for x, y in zip(steps, steps[1:])), name
+    segs, paths = rs.parse_gfa_paths(a)
+    assert len(paths) == 16 and 19000 < sum(len(s) for s in segs.values()) < 21500
+
+
 def test_host_index_small_graph_vectors(tmp_path, oracle):
     """src/index.rs:761-824 (linearisation, NodeRefs) and 1109-1129 (ACT -> F0..F3) through the C++ builder"""
     gfa = tmp_path / "simple.gfa"
