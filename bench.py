@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--reads", type=int, default=10000, help="reads per GPU (default: the full config #3 batch)")
     ap.add_argument("--read-len", type=int, default=10000)
     ap.add_argument("--cpu-sample", type=int, default=40, help="reads of the workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--workload", choices=["config3", "config4", "config5"], default="config3",
+                    help="config3 (default, the headline line): DRB1-3123; config4: nine merged HLA loci; config5: 1 Mbp synthetic "
+                         "pangenome (same read model; extra measurements, not the driver's bench line)")
     args = ap.parse_args()
 
     import torch
@@ -66,6 +69,18 @@ def main():
 
     # ---- workload: identical generator on every rank, different seed per rank (different reads, same shape)
     t0 = time.time()
+    GFA = globals()["GFA"]
+    wl_name = "config3: HLA DRB1-3123 graph"
+    if args.workload != "config3":
+        import tempfile
+
+        GFA = os.path.join(tempfile.mkdtemp(prefix="vga_bench_"), args.workload + ".gfa")
+        if args.workload == "config4":
+            nn, ne, nb_ = pkg.readsim.config4_graph(os.path.join(ROOT, "tests", "golden", "data"), GFA)
+            wl_name = "config4: 9 forward-acyclic HLA-zoo loci merged (%d nodes, %d bp)" % (nn, nb_)
+        else:
+            nn, ne, nb_ = pkg.readsim.synth_pangenome(GFA)
+            wl_name = "config5: synthetic pangenome (%d nodes, %d bp)" % (nn, nb_)
     reads = pkg.readsim.simulate_reads(GFA, args.reads, args.read_len, 0.03, 0.03, 0.04, seed=pkg.sharding.bench_seed(rank))
     seqs = [r.seq for r in reads]
     t_gen = time.time() - t0
@@ -126,7 +141,8 @@ def main():
     if os.path.exists(tp):
         try:
             tj = json.load(open(tp))
-            if tj.get("kernel") == dom and tj.get("reads") == args.reads and tj.get("read_len") == args.read_len:
+            if (tj.get("kernel") == dom and tj.get("reads") == args.reads and tj.get("read_len") == args.read_len
+                    and args.workload == "config3"):
                 # measured with rocprofv3 PMC passes (profiles/traffic.json), per step; per launch = / launches per step
                 traffic = int(tj["hbm_bytes_per_step"] / max(d["launches"] / args.steps, 1))
         except Exception:
@@ -183,8 +199,8 @@ def main():
         "vs_baseline": None,
         "dtype": "int32+f64",
         "data": "synthetic",
-        "config": {"workload": "config3: HLA DRB1-3123 graph, k=11, %d x %d bp ONT-profile reads per GPU, --also-align"
-                               % (args.reads, args.read_len),
+        "config": {"workload": "%s, k=11, %d x %d bp ONT-profile reads per GPU, --also-align"
+                               % (wl_name, args.reads, args.read_len),
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "sharding": "reads, replicated index, no collective"},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -2163,6 +2163,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     int t_total = vga_timer_begin(ctx, "poa_total", 0);
     struct sub_t { uint64_t i0, i1; double raw_est; int slot; int oset; bool use32 = false; };
     hipError_t launch_err = hipSuccess;
+    // a sub-batch is closed once it holds this many problems and this many estimated DP cells (or its pool half is full)
+    uint64_t sub_problems = 4096;  // measured on configs 3-5 (tests/prof_sub_sweep.sh): 3072..5120 is flat, uncapped loses 40 % on config 5
+    double sub_cells = 2e9;
+    if (const char *e = getenv("VGA_POA_SUB")) sub_problems = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
     uint64_t in_flight_other = 0;  // problems of the sub-batch on the other stream (they share the GPU with this launch)
     // stage, upload and enqueue DP + traceback + result copies of a sub-batch that starts at launch position i0 and ends
     // at cap at the latest
@@ -2171,15 +2175,19 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         poa_slot &S = W.slot[slot];
         uint8_t *pool_base = W.pool + (uint64_t)slot * half_pool;
         const double budget = (double)half_pool * 0.92;
-        double used_est = 0, raw_est = 0;
+        double used_est = 0, raw_est = 0, cells_est = 0;
         uint64_t i1 = i0;
         while (i1 < cap) {
             if (!ready[order[i1]]) ensure(i1, std::min<uint64_t>(cap, i1 + 256));
             if (malformed) break;
             const double e = est[order[i1]] * W.pool_scale + 3.0 * (double)POA_CHUNK;
             if (i1 > i0 && used_est + e > budget) break;
+            // the pool is not the only reason to cut: the host work either side of a sub-batch (subgraphs and node
+            // tables before, CIGAR / cs strings after) only overlaps with the GPU when there are several sub-batches
+            if (i1 - i0 >= sub_problems && cells_est >= sub_cells) break;
             used_est += e;
             raw_est += est[order[i1]];
+            cells_est += (double)G[order[i1]].N * estw[order[i1]];
             i1++;
         }
         auto chk = [&](hipError_t e) { if (e != hipSuccess && launch_err == hipSuccess) launch_err = e; };
