@@ -57,6 +57,8 @@ struct poa_prob {
     uint32_t w;      // adaptive band half-width: wb + floor(wf * qlen), computed on the host in double
     uint32_t n_nodes;  // node-table entries incl. the source
     uint32_t ring_rows;  // value rows of node-end rows live in a ring of this many worst-case rows (k_poa_dp_pk)
+    uint32_t flags;      // bit 0: too large for an arena (k_poa_dp_pk in arena mode reports POA_ST_POOL at once)
+    uint32_t pad;
 };
 
 struct poa_row {          // per DP row, 48 B
@@ -659,6 +661,169 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
     outs[pi].nops = (uint32_t)nops;
 }
 
+// K4b, cooperative form (the default): one wave per problem.  The walk itself is a chain of dependent reads (row
+// record -> direction byte -> predecessor), two HBM round trips per operation when one lane does it alone.  Here the
+// 64 lanes stage, in two round trips, what the next stretch of the walk can need -- the records of rows i .. i-63
+// and, for each of them, a TB_WIN-byte window of its direction row around the column the path would reach it at if
+// every row in between lay on the path (fewer columns are consumed when rows are skipped, so the window starts just
+// below that column and extends above it); rows with several predecessors also stage the window of their predecessor
+// choice plane and their first four predecessors -- and then all lanes walk in lock step out of LDS until the path
+// leaves the staged rows or a window (30-60 operations on the HLA graphs).  Same outputs as k_poa_traceback.
+#define TB_WIN 32
+struct tb_lds {  // 6 912 B: what one wave stages per stretch
+    int beg[64], end[64], ws[64];
+    uint64_t doff[64];
+    uint32_t pred[64], np[64];
+    uint32_t dir[64][TB_WIN / 4], pl1[64][TB_WIN / 4], pr4[64][4];
+};
+// LDS traffic of one wave is processed in program order: between the staging stores and the walk's loads (other
+// lanes' data) the wave only has to wait for its own stores to be issued -- no s_barrier, so the function can run in
+// one wave of a larger workgroup whose other waves have finished
+__device__ __forceinline__ void tb_wave_sync()
+{
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+// every lane of the wave calls this with the same arguments (lane = its index); status / start_row are the DP's result
+__device__ __forceinline__ void poa_traceback_wave(
+    tb_lds &T, const int lane, const poa_prob &pb, const poa_row *__restrict__ rows, const uint32_t *__restrict__ preds,
+    const uint8_t *__restrict__ pool, poa_out &O, uint8_t *__restrict__ ops, uint32_t *__restrict__ orow, const int code_xor,
+    const int status, const uint32_t start_row)
+{
+    if (status != POA_ST_OK) {
+        if (lane == 0) O.nops = 0;
+        return;
+    }
+    const uint32_t cap = (uint32_t)std::min<uint64_t>((uint64_t)pb.N + pb.qlen + 2, 0xffffffffu);
+    uint8_t *po = ops + pb.ops0;
+    uint32_t *pr = orow + pb.ops0;
+    uint32_t i = start_row;
+    int j = (int)pb.qlen;
+    int st = 0;  // 0 H, 1 E1, 2 E2, 3 F1, 4 F2, 5 Ht
+    uint32_t nops = 0;
+    bool bad = false;
+    uint32_t my_op = 0, my_row = 0;  // lane l keeps operation number (64 m + l) until the wave stores 64 of them together
+    auto emit = [&](uint32_t op, uint32_t row) {
+        if ((uint32_t)lane == (nops & 63u)) { my_op = op; my_row = row; }
+        nops++;
+        if ((nops & 63u) == 0) {
+            po[nops - 64 + lane] = (uint8_t)my_op;
+            pr[nops - 64 + lane] = my_row;
+        }
+    };
+    while (i > 0 && !bad) {
+        // ---- stage rows i0 .. i0 - 63
+        const uint32_t i0 = i;
+        tb_wave_sync();  // the previous stretch is done with the LDS arrays
+        if ((uint32_t)lane < i0) {
+            const uint32_t r = i0 - (uint32_t)lane;
+            const poa_row rw = rows[pb.row0 + r];
+            const int bal = rw.beg & ~3;
+            const int W = (rw.end - bal + 1 + 3) & ~3;
+            int ws = ((j - lane - 8) - bal) & ~3;  // window start relative to bal
+            if (ws > W - TB_WIN) ws = W - TB_WIN;
+            if (ws < 0) ws = 0;
+            const uint8_t *drow = pool + rw.doff;
+#pragma unroll
+            for (int d = 0; d < TB_WIN / 4; d++) {
+                const int cc = ws + 4 * d;
+                T.dir[lane][d] = cc < W ? *(const uint32_t *)(drow + cc) : 0u;
+            }
+            if (rw.npred > 1) {
+#pragma unroll
+                for (int d = 0; d < TB_WIN / 4; d++) {
+                    const int cc = ws + 4 * d;
+                    T.pl1[lane][d] = cc < W ? *(const uint32_t *)(drow + (uint64_t)W + cc) : 0u;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) T.pr4[lane][q] = (uint32_t)q < rw.npred ? preds[pb.pred0 + rw.pred + q] : 0u;
+            }
+            T.beg[lane] = rw.beg;
+            T.end[lane] = rw.end;
+            T.ws[lane] = bal + ws;
+            T.doff[lane] = rw.doff;
+            T.pred[lane] = rw.pred;
+            T.np[lane] = rw.npred;
+        }
+        tb_wave_sync();
+        // ---- walk out of LDS, every lane the same steps
+        while (i > 0) {
+            const uint32_t t = i0 - i;
+            if (t >= 64) break;
+            const int beg = T.beg[t], end = T.end[t];
+            if (j < beg || j > end) { bad = true; break; }
+            const int off = j - T.ws[t];
+            if (off < 0 || off >= TB_WIN) break;  // t > 0 here: the window of row i0 was placed around j
+            const uint32_t npred = T.np[t];
+            const bool first = npred != 0;
+            const int np = first ? (int)npred : 1;
+            const int code = (int)((T.dir[t][off >> 2] >> (8 * (off & 3))) & 0xffu) ^ code_xor;
+            // direction byte: [1:0] source of Ht (M, E1, E2), [3:2] E1/E2 opened here, [4] F1 > Ht, [5] F2 > max(Ht, F1),
+            // [7:6] F1/F2 opened here
+            const int hts = code & 3;
+            const int fsel = (code & 32) ? 2 : ((code >> 4) & 1);
+            const int hs = fsel ? 2 + fsel : hts;
+            const int src = st == 0 ? hs : (st == 5 ? hts : st);
+            if (nops + 1 >= cap) { bad = true; break; }
+            if (src <= 2) {
+                uint32_t p = i - 1;
+                if (first) {
+                    p = T.pred[t];
+                    if (np > 1) {
+                        int tt;
+                        if (src == 0) tt = (int)((T.pl1[t][off >> 2] >> (8 * (off & 3))) & 0xffu);
+                        else {
+                            const int bal = beg & ~3;
+                            const uint64_t W = (uint64_t)((end - bal + 1 + 3) & ~3);
+                            tt = pool[T.doff[t] + (src == 1 ? 2 : 3) * W + (uint64_t)(j - bal)];
+                        }
+                        p = tt < 4 ? T.pr4[t][tt] : preds[pb.pred0 + p + tt];
+                    }
+                }
+                p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+                if (src == 0) {
+                    if (j < 1) { bad = true; break; }
+                    emit(0, i);
+                    i = p; j -= 1; st = 0;
+                } else {
+                    const int open = (code >> (src == 1 ? 2 : 3)) & 1;
+                    emit(2, i);
+                    st = open ? 0 : src;
+                    i = p;
+                }
+            } else {
+                const int open = (code >> (src == 3 ? 6 : 7)) & 1;
+                if (j - 1 < beg) { bad = true; break; }
+                emit(1, 0);
+                st = open ? 5 : src;
+                j -= 1;
+            }
+        }
+    }
+    // the rest of the query is an insertion before the first aligned row
+    if (!bad && j > 0 && (uint64_t)nops + (uint64_t)j >= cap) bad = true;
+    if (bad) {
+        if (lane == 0) { O.status = POA_ST_TRACE; O.nops = 0; }
+        return;
+    }
+    const uint32_t base = nops & ~63u;
+    if ((uint32_t)lane < (nops & 63u)) { po[base + lane] = (uint8_t)my_op; pr[base + lane] = my_row; }
+    for (uint32_t x = (uint32_t)lane; x < (uint32_t)j; x += 64) { po[nops + x] = 1; pr[nops + x] = 0; }
+    if (lane == 0) O.nops = nops + (uint32_t)j;
+}
+
+__global__ __launch_bounds__(64) void k_poa_traceback_wave(
+    uint32_t n, const poa_prob *__restrict__ probs, const poa_row *__restrict__ rows,
+    const uint32_t *__restrict__ preds, const uint8_t *__restrict__ pool, poa_out *__restrict__ outs,
+    uint8_t *__restrict__ ops, uint32_t *__restrict__ orow, int code_xor)
+{
+    __shared__ tb_lds T;
+    const uint32_t pi = blockIdx.x;
+    if (pi >= n) return;
+    const poa_prob pb = probs[pi];
+    poa_traceback_wave(T, (int)threadIdx.x, pb, rows, preds, pool, outs[pi], ops, orow, code_xor, outs[pi].status, outs[pi].row);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K4, packed form (the default).  Same algorithm and outputs as k_poa_dp_lds; the differences are about
 // residency:
@@ -738,9 +903,10 @@ template <int NT, bool STAMP = false, bool DEF = false, int CPT = 4, bool H16 = 
 __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
     const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
     const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
-    poa_dev_params P, poa_row *rows, uint8_t *pool, unsigned long long *pool_next, uint64_t pool_size,
+    poa_dev_params P, poa_row *rows, uint8_t *pool_arg, unsigned long long *pool_next_arg, uint64_t pool_size_arg,
     poa_out *__restrict__ outs, uint32_t lds_cols, uint32_t hg_cols, uint32_t win_mask, int g1bits_arg,
-    unsigned long long *stamps = nullptr)
+    uint8_t *__restrict__ tb_ops, uint32_t *__restrict__ tb_orow, uint32_t n_arenas, uint64_t arena_size,
+    unsigned long long *arena_ctr, uint32_t *arena_flag, unsigned long long *stamps = nullptr)
 {
     constexpr int QPT = CPT / 4;  // quads (one LDS int4 / one direction dword each) per lane and step
     constexpr int NW = NT / 64;
@@ -827,6 +993,47 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
     const uint4 *ntab = node_tab + pb.node0;
     const uint32_t *plist = preds + pb.pred0;
     poa_row *R = rows + pb.row0;
+
+    // ---- where this problem's direction and value rows go.  Classic mode (n_arenas == 0): chunks of the launch's pool
+    // segment, handed out by one atomic counter; the segment is recycled when the whole launch has been traced back.
+    // Arena mode: the pool is cut into n_arenas equal arenas; a workgroup takes a free one, is the only user of its bump
+    // counter, traces its problem back itself (tb_ops) and gives the arena back -- so launches of any size can follow
+    // each other on several streams and the GPU stays full across them.
+    uint8_t *pool = pool_arg;
+    unsigned long long *pool_next = pool_next_arg;
+    uint64_t pool_size = pool_size_arg;
+    uint32_t arena = 0;
+    if (n_arenas) {
+        int got = -1;
+        if (!(pb.flags & 1u)) {
+            if (tid == 0) {
+                uint32_t a = (uint32_t)(((uint64_t)blockIdx.x * 2654435761ull) % n_arenas);
+                // every arena is held by a running workgroup that will give it back: wait (bounded, as a fail-safe)
+                for (uint32_t tries = 0; tries < (1u << 24); tries++) {
+                    if (atomicCAS(&arena_flag[a], 0u, 1u) == 0u) { got = (int)a; break; }
+                    a = a + 1 == n_arenas ? 0 : a + 1;
+                    if ((tries & 15u) == 15u) __builtin_amdgcn_s_sleep(64);
+                }
+                if (got >= 0) (void)atomicExch(&arena_ctr[got], 0ull);
+                sSink[1] = got;
+            }
+            __syncthreads();
+            got = __builtin_amdgcn_readfirstlane(sSink[1]);
+        }
+        if (got < 0) {
+            if (tid == 0) {
+                poa_out &O = outs[blockIdx.x];
+                O.t_begin = t_begin; O.t_end = t_begin; O.cells = 0; O.vcells = 0; O.maxw = 0; O.nops = 0;
+                O.score = POA_NEG; O.row = 0; O.status = POA_ST_POOL;
+            }
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        arena = (uint32_t)got;
+        pool = pool_arg + (uint64_t)arena * arena_size;
+        pool_next = arena_ctr + arena;
+        pool_size = arena_size;
+    }
 
     const int g1bits = DEF ? 3 : g1bits_arg;
     const int o1 = DEF ? 4 : P.o1, e1 = DEF ? 2 : P.e1, o2 = DEF ? 24 : P.o2, e2 = DEF ? 1 : P.e2;
@@ -1820,30 +2027,45 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
         if (stamps && blockIdx.x < 64 && (tid == 0 || tid == 128))
             for (int s = 0; s < 8; s++) stamps[(tid ? 64 * 8 : 0) + blockIdx.x * 8 + s] = tacc[s];
     }
-    if (tid == 0) {
+    if (tid >= 64) return;
+    // ---- wave 0: the result record, then (tb_ops != nullptr) the traceback of this problem, out of the same LDS -- the
+    // direction rows were written by this workgroup, through this CU's L1, and the barrier above ordered them
+    int status = POA_ST_OK;
+    uint32_t start_row = 0;
+    {
         const lead_t L = lead_load();
         const bool failed = L.failed != 0;
         poa_out &O = outs[blockIdx.x];
-        O.t_begin = t_begin;
-        O.t_end = __builtin_amdgcn_s_memrealtime();
-        O.cells = L.cells;
-        O.vcells = L.vcells;
-        O.maxw = (uint32_t)L.maxw;
-        if (range_stop) {
-            O.status = POA_ST_RANGE;
-            O.score = POA_NEG;
-            O.row = 0;
-        } else if (failed) {
-            O.status = POA_ST_POOL;
-            O.score = POA_NEG;
-            O.row = 0;
-        } else {
-            const int bestv = L.sink_best;
-            const uint32_t brow = L.sink_row;
-            const bool have = L.sink_have != 0;
-            O.score = bestv;
-            O.row = brow;
-            O.status = (have && bestv > POA_NEG / 2) ? POA_ST_OK : POA_ST_NOALN;
+        if (range_stop) status = POA_ST_RANGE;
+        else if (failed) status = POA_ST_POOL;
+        else {
+            start_row = L.sink_row;
+            status = (L.sink_have != 0 && L.sink_best > POA_NEG / 2) ? POA_ST_OK : POA_ST_NOALN;
+        }
+        if (tid == 0) {
+            O.t_begin = t_begin;
+            O.cells = L.cells;
+            O.vcells = L.vcells;
+            O.maxw = (uint32_t)L.maxw;
+            O.score = (range_stop || failed) ? POA_NEG : L.sink_best;
+            O.row = start_row;
+            O.status = status;
+        }
+    }
+    if (tb_ops) {
+        status = __builtin_amdgcn_readfirstlane(status);
+        start_row = (uint32_t)__builtin_amdgcn_readfirstlane((int)start_row);
+        poa_traceback_wave(*(tb_lds *)(smem + HDR), tid, pb, rows, preds, pool, outs[blockIdx.x], tb_ops, tb_orow, H16 ? 0xC0 : 0,
+                           status, start_row);
+    }
+    if (tid == 0) {
+        outs[blockIdx.x].t_end = __builtin_amdgcn_s_memrealtime();
+        if (n_arenas) {
+            // bytes this problem took (statistics of the launch), then hand the arena on
+            const unsigned long long used = atomicAdd(pool_next, 0ull);
+            (void)atomicAdd(pool_next_arg, used < arena_size ? used : (unsigned long long)arena_size);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            (void)atomicExch(&arena_flag[arena], 0u);
         }
     }
 }
@@ -1851,7 +2073,8 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
 static inline size_t poa_pk_lds_bytes(uint32_t hg_cols, uint32_t lds_cols, int nt, bool h16 = false)
 {
     const int nw = nt / 64;
-    return (h16 ? 3ull : 4ull) * hg_cols + ((lds_cols / 2 + 15u) & ~15u) + (size_t)(3 * nw + 1 + 4 + 6 + 1) * 16 + 16;
+    // (the fused traceback reuses the row-state area: at least sizeof(tb_lds) behind the header)
+    return std::max<size_t>((h16 ? 3ull : 4ull) * hg_cols + ((lds_cols / 2 + 15u) & ~15u), sizeof(tb_lds)) + (size_t)(3 * nw + 1 + 4 + 6 + 1) * 16 + 16;
 }
 
 static inline uint32_t poa_lds_cols(uint32_t max_q) { return ((max_q + 1 + 15u) & ~15u) + 16u; }
@@ -1977,6 +2200,8 @@ struct poa_ws {
     poa_slot slot[POA_SLOTS];
     vga_dbuf<unsigned long long> d_next;
     vga_hbuf<unsigned long long> h_next;
+    vga_dbuf<unsigned long long> d_arena_ctr;  // arena mode: one bump counter and one busy flag per arena
+    vga_dbuf<uint32_t> d_arena_flag;
     uint8_t *pool = nullptr;
     uint64_t pool_size = 0;
     hipStream_t extra[POA_SLOTS] = {};  // streams of slots 1.. (slot 0 runs on the context's stream)
@@ -2038,7 +2263,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         const char *force = getenv("VGA_POA_KERNEL");
         const bool unpacked = g1b + g2b > 8 || (force && strstr(force, "unpacked"));
         // the packed kernel keeps a 4096-column window of the row state; the unpacked one every column
-        const uint32_t hg_need = std::min<uint32_t>(lds_cols_all, 4096);
+        const uint32_t hg_need = (force && strstr(force, "full")) ? lds_cols_all : std::min<uint32_t>(lds_cols_all, 4096);
         const size_t need = unpacked ? poa_lds_bytes(lds_cols_all, 128) : poa_pk_lds_bytes(hg_need, lds_cols_all, 128);
         if (need > 160 * 1024 - 256)
             return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query of %u bases does not fit the LDS-resident POA kernel (limit ~280 kbp, ~22 kbp with large gap penalties)", max_q);
@@ -2154,6 +2379,40 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     }
     const uint64_t half_pool = (W.pool_size / (uint64_t)n_slots) & ~(POA_CHUNK - 1);  // one slot's segment of the pool
 
+    // ---- arena mode (the default with the packed kernel and its fused traceback): the whole pool is cut into arenas, a
+    // workgroup holds one from its first row to the end of its traceback.  No launch has to wait for another one's
+    // pool segment, so sub-batches are cut for the host pipeline only and workgroups of consecutive launches fill the
+    // CUs back to back.  Problems that would not fit an arena (and the ones that turn out not to) are collected and run
+    // at the end in classic mode, which gives each of them as much of the pool as it needs.
+    const char *force_k = getenv("VGA_POA_KERNEL");
+    int g1b_ = 0, g2b_ = 0;
+    while ((1 << g1b_) <= params->gap_open1 + params->gap_ext1) g1b_++;
+    while ((1 << g2b_) <= params->gap_open2 + params->gap_ext2) g2b_++;
+    const bool packed_k = g1b_ + g2b_ <= 8 && !(force_k && strstr(force_k, "unpacked"));
+    // traceback: fused into the packed DP kernel (default), or VGA_POA_TB=wave / lane: a kernel of its own after the DP
+    const bool tb_lane = getenv("VGA_POA_TB") && strstr(getenv("VGA_POA_TB"), "lane");
+    const bool tb_fused = !getenv("VGA_POA_TB") || strstr(getenv("VGA_POA_TB"), "fused");
+    uint32_t n_arenas = 0;
+    uint64_t arena_size = 0;
+    if (packed_k && tb_fused && !getenv("VGA_POA_STAMPS") && !(getenv("VGA_POA_ARENAS") && atoi(getenv("VGA_POA_ARENAS")) == 0)) {
+        // an arena should hold the largest of the probed problems with a margin; more arenas than workgroups can be
+        // resident (16 per CU at most) are of no use, fewer than 4 per CU would leave most of the GPU waiting for one
+        double big = 0;
+        for (uint64_t i = 0; i < n_probe; i++) big = std::max(big, est[order[i]]);
+        const double want_arena = big * W.pool_scale * 1.3 + 4.0 * (double)POA_CHUNK;
+        uint64_t na = (uint64_t)((double)W.pool_size / want_arena);
+        na = std::min<uint64_t>(na, 16ull * (uint64_t)ctx->n_cu);
+        if (const char *e = getenv("VGA_POA_ARENAS")) na = std::min<uint64_t>(na, strtoull(e, nullptr, 10));
+        if (na >= 4ull * (uint64_t)ctx->n_cu || na >= n) {
+            n_arenas = (uint32_t)na;
+            arena_size = (W.pool_size / na) & ~(POA_CHUNK - 1);
+            POA_CHECK(W.d_arena_ctr.reserve(n_arenas));
+            POA_CHECK(W.d_arena_flag.reserve(n_arenas));
+            POA_CHECK(hipMemset(W.d_arena_flag.p, 0, n_arenas * sizeof(uint32_t)));
+        }
+    }
+    if (tr.on) fprintf(stderr, "[vga-trace] poa: pool %.1f GB, %u arenas of %.1f MB\n", (double)W.pool_size / 1e9, n_arenas, (double)arena_size / 1e6);
+
     poa_dev_params P;
     P.match = params->match; P.mismatch = params->mismatch; P.o1 = params->gap_open1; P.e1 = params->gap_ext1;
     P.o2 = params->gap_open2; P.e2 = params->gap_ext2; P.banded = params->wb >= 0;
@@ -2161,19 +2420,22 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     bool packed_all = true;  // value rows are 4 B per cell with the packed kernel, 6 B otherwise (byte model)
     bool h16_all = true;     // ... and 3 B with 16-bit row state
     int t_total = vga_timer_begin(ctx, "poa_total", 0);
-    struct sub_t { uint64_t i0, i1; double raw_est; int slot; int oset; bool use32 = false; };
+    struct sub_t { uint64_t i0, i1; double raw_est; int slot; int oset; bool use32 = false; bool arena = false; };
     hipError_t launch_err = hipSuccess;
     // a sub-batch is closed once it holds this many problems and this many estimated DP cells (or its pool half is full)
-    uint64_t sub_problems = 4096;  // measured on configs 3-5 (tests/prof_sub_sweep.sh): 3072..5120 is flat, uncapped loses 40 % on config 5
+    // measured on configs 3-5 (tests/prof_sub_sweep.sh, tests/prof_ab.sh).  Classic mode: 3072..5120 is flat, uncapped
+    // loses 40 % on config 5.  Arena mode: launches share the GPU seamlessly, so shorter ones only cost when two of them
+    // cannot fill it (1024: -12 % on config 3); 2048 is best on all three.
+    uint64_t sub_problems = n_arenas ? 2048 : 4096;
     double sub_cells = 2e9;
     if (const char *e = getenv("VGA_POA_SUB")) sub_problems = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
     uint64_t in_flight_other = 0;  // problems of the sub-batch on the other stream (they share the GPU with this launch)
     // stage, upload and enqueue DP + traceback + result copies of a sub-batch that starts at launch position i0 and ends
     // at cap at the latest
-    auto launch = [&](uint64_t i0, uint64_t cap, int slot, bool use32) -> sub_t {
+    auto launch = [&](uint64_t i0, uint64_t cap, int slot, bool use32, bool arena) -> sub_t {
         hipStream_t st = sarr[slot];  // shadows the context's stream inside this lambda
         poa_slot &S = W.slot[slot];
-        uint8_t *pool_base = W.pool + (uint64_t)slot * half_pool;
+        uint8_t *pool_base = arena ? W.pool : W.pool + (uint64_t)slot * half_pool;
         const double budget = (double)half_pool * 0.92;
         double used_est = 0, raw_est = 0, cells_est = 0;
         uint64_t i1 = i0;
@@ -2181,17 +2443,19 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             if (!ready[order[i1]]) ensure(i1, std::min<uint64_t>(cap, i1 + 256));
             if (malformed) break;
             const double e = est[order[i1]] * W.pool_scale + 3.0 * (double)POA_CHUNK;
-            if (i1 > i0 && used_est + e > budget) break;
+            if (!arena && i1 > i0 && used_est + e > budget) break;
             // the pool is not the only reason to cut: the host work either side of a sub-batch (subgraphs and node
             // tables before, CIGAR / cs strings after) only overlaps with the GPU when there are several sub-batches
             if (i1 - i0 >= sub_problems && cells_est >= sub_cells) break;
             used_est += e;
-            raw_est += est[order[i1]];
+            // (arena mode: problems that are sent on to the classic pass take no arena and do not count)
+            if (!arena || e * 1.1 <= (double)arena_size) raw_est += est[order[i1]];
             cells_est += (double)G[order[i1]].N * estw[order[i1]];
             i1++;
         }
         auto chk = [&](hipError_t e) { if (e != hipSuccess && launch_err == hipSuccess) launch_err = e; };
         bool sub_h16 = false;  // this sub-batch runs the 16-bit DP kernel
+        bool sub_fused = false;  // ... and its DP kernel does the traceback as well
         if (malformed || i1 == i0) return {i0, i0, 0.0, slot, 0};
         const int oset = (int)(S.uses++ & 1u);
         poa_slot::out_set &O = S.outs[oset];
@@ -2205,6 +2469,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             pb.node0 = tot_nodes; pb.pred0 = tot_preds; pb.sink0 = tot_sink; pb.q0 = tot_q; pb.ops0 = tot_ops; pb.row0 = tot_rows;
             pb.seq0 = tot_seq;
             pb.n_sink = (uint32_t)g.sinks.size(); pb.qlen = g.qlen; pb.N = g.N; pb.n_nodes = (uint32_t)g.ntab.size(); pb.ring_rows = g.life + 1;
+            pb.flags = arena && (est[p] * W.pool_scale + 3.0 * (double)POA_CHUNK) * 1.1 > (double)arena_size ? 1u : 0u;
+            pb.pad = 0;
             pb.w = params->wb < 0 ? g.qlen : (uint32_t)((int64_t)params->wb + (int64_t)(params->wf * (double)g.qlen));
             tot_nodes += g.ntab.size();
             tot_preds += g.preds.size();
@@ -2260,6 +2526,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             const bool h16 = packed && def_pen && !use32 && getenv("VGA_POA_H16") && atoi(getenv("VGA_POA_H16")) != 0;
             h16_all = h16_all && h16;
             sub_h16 = h16;
+            sub_fused = packed && tb_fused && !getenv("VGA_POA_STAMPS");
             // LDS column window (packed kernel): 4096 columns keep almost every row of a 10 kbp read resident (its widest
             // rows, a few per cent, take the HBM detour described in the kernel) and let seven workgroups share a CU
             // instead of three.  Queries that fit a smaller array anyway keep every column.
@@ -2303,7 +2570,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             (void)hipGetLastError();  // a launch failure below must be this launch's, not an older ignored status
 #define POA_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_sink.p, P, S.d_rows.p, pool_base,          \
                  W.d_next.p + slot, half_pool, S.d_outs.p, lds_cols
-#define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, g1bits
+#define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, g1bits, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr), \
+                    (arena ? n_arenas : 0u), arena_size, W.d_arena_ctr.p, W.d_arena_flag.p
             if (packed) {
                 if (getenv("VGA_POA_STAMPS") && nt == 512) {
                     // diagnostic: per-segment cycle shares of the first 64 workgroups (tid 0's wave), printed to stderr
@@ -2365,21 +2633,27 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         }
         vga_timer_end(ctx, t_dp);
         int t_tb = vga_timer_begin(ctx, "poa_traceback", 0, st);
-        hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
-                           pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, sub_h16 ? 0xC0 : 0);
+        if (sub_fused) {
+            // the DP kernel's first wave already walked each problem back
+        } else if (tb_lane)  // VGA_POA_TB=lane: the one-lane-per-problem walk (diagnostic / cross-check)
+            hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
+                               pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, sub_h16 ? 0xC0 : 0);
+        else
+            hipLaunchKernelGGL(k_poa_traceback_wave, dim3(nb), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
+                               pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, sub_h16 ? 0xC0 : 0);
         vga_timer_end(ctx, t_tb);
         chk(hipMemcpyAsync(O.h_outs.p, S.d_outs.p, nb * sizeof(poa_out), hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(W.h_next.p + slot, W.d_next.p + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(O.h_ops.p, S.d_ops.p, tot_ops, hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(O.h_orow.p, S.d_orow.p, tot_ops * 4, hipMemcpyDeviceToHost, st));
-        return {i0, i1, raw_est, slot, oset};
+        return {i0, i1, raw_est, slot, oset, false, arena};
     };
     // host: CIGAR / cs / node path of one problem from the raw op stream (reverse order on the device)
     auto post_one = [&](const poa_slot::out_set &S, uint64_t i0, uint64_t i) {
         const uint32_t p = order[i];
         poa_item &it = out[p];
         const poa_out &ho = S.h_outs.p[i - i0];
-        if (ho.status == POA_ST_RANGE) return;  // re-run later
+        if (ho.status == POA_ST_RANGE || ho.status == POA_ST_POOL) return;  // re-run later (16-bit range / arena too small)
         it.ok = ho.status == POA_ST_OK ? 1 : 0;
         it.score = ho.score;
         it.n_cells = ho.cells;
@@ -2449,10 +2723,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     // host threads prepare the problems of the next sub-batch (the caller's subgraphs, node tables) and turn the op
     // streams of the sub-batch that just finished into CIGAR / cs strings.
     int rc_final = VGA_OK;
-    struct seg_t { uint64_t first, second; bool use32; };
+    struct seg_t { uint64_t first, second; bool use32; bool arena; };
     std::vector<seg_t> todo;  // used as a stack of [begin, end) ranges of launch positions, front = back()
-    todo.push_back({0, n, false});
+    todo.push_back({0, n, false, n_arenas != 0});
     std::vector<uint32_t> retry32;  // problems the 16-bit kernel gave up on (POA_ST_RANGE)
+    std::vector<uint32_t> too_big;  // problems that did not fit an arena: classic mode once the arena launches are done
     std::vector<sub_t> inflight;
     bool slot_busy[POA_SLOTS] = {};
     uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
@@ -2461,9 +2736,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             int slot = 0;
             while (slot_busy[slot]) slot++;
             auto &seg = todo.back();
+            // arena launches use the whole pool, classic ones its per-slot segments: never both at a time
+            if (!inflight.empty() && inflight.front().arena != seg.arena) break;
             in_flight_other = 0;
             for (const sub_t &o : inflight) in_flight_other += o.i1 - o.i0;
-            sub_t sb = launch(seg.first, seg.second, slot, seg.use32);
+            sub_t sb = launch(seg.first, seg.second, slot, seg.use32, seg.arena);
             sb.use32 = seg.use32;
             if (sb.i1 == sb.i0) break;
             if (sb.i1 >= seg.second) todo.pop_back();
@@ -2483,12 +2760,15 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         if (launch_err != hipSuccess) break;
         bool pool_fail = false;
         for (uint64_t i = cur.i0; i < cur.i1; i++)
-            if (S.h_outs.p[i - cur.i0].status == POA_ST_POOL) pool_fail = true;
+            if (S.h_outs.p[i - cur.i0].status == POA_ST_POOL) {
+                if (cur.arena) too_big.push_back(order[i]);
+                else pool_fail = true;
+            }
         if (pool_fail) {
             slot_busy[cur.slot] = false;
             if (cur.i1 - cur.i0 == 1 && W.pool_scale >= 8.0) { rc_final = VGA_ERR_POOL; break; }
             W.pool_scale = std::min(16.0, W.pool_scale * 1.7);
-            todo.push_back({cur.i0, cur.i1, cur.use32});  // enqueue it again, in smaller pieces
+            todo.push_back({cur.i0, cur.i1, cur.use32, false});  // enqueue it again, in smaller pieces
             fill();
             continue;
         }
@@ -2537,7 +2817,14 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             for (uint32_t p : retry32) order.push_back(p);
             if (tr.on) fprintf(stderr, "[vga-trace] poa: %zu problems re-run with 32-bit rows\n", retry32.size());
             retry32.clear();
-            todo.push_back({a, order.size(), true});
+            todo.push_back({a, order.size(), true, n_arenas != 0});
+        }
+        if (todo.empty() && inflight.empty() && !too_big.empty()) {
+            const uint64_t a = order.size();
+            for (uint32_t p : too_big) order.push_back(p);
+            if (tr.on) fprintf(stderr, "[vga-trace] poa: %zu problems did not fit an arena of %.1f MB: classic pass\n", too_big.size(), (double)arena_size / 1e6);
+            too_big.clear();
+            todo.push_back({a, order.size(), cur.use32, false});
         }
         // refill the GPU first (the new sub-batch's results go to the slot's other result set), then post-process
         slot_busy[cur.slot] = false;
@@ -2547,7 +2834,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             parallel_for(cnt, [&](uint64_t t) { post_one(S, a0, a0 + t); });
             for (uint64_t i = cur.i0; i < cur.i1; i++) {
                 const poa_out &ho = S.h_outs.p[i - cur.i0];
-                if (ho.status == POA_ST_RANGE) continue;
+                if (ho.status == POA_ST_RANGE || ho.status == POA_ST_POOL) continue;
                 all_cells += ho.cells; all_vcells += ho.vcells; all_ops += ho.nops;
                 all_rows += G[order[i]].N; all_q += G[order[i]].qlen;
             }
