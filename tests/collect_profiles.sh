@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collects the round's evidence on the GPU box into gpurun_out/prof_<tag>/ (copy the summaries into profiles/ afterwards):
+#   1. bench.py plain (the driver's command), 2. the same under rocprofv3 --kernel-trace --stats,
+#   3./4. PMC passes FETCH_SIZE and WRITE_SIZE (separate runs, kernel-trace only), one bench step each.
+# usage (on the GPU box, via gpurun):  bash tests/collect_profiles.sh v7
+set -e
+TAG=${1:-vX}
+REPO=$GRAFT_REPO_ROOT
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
+echo "bench done"; tail -c 600 $OUT/bench.json
+timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 $REPO/bench.py --cpu-sample 0 > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+echo "kernel trace done"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_poa_dp" -d $OUT/pmc_$c -o pmc --output-format csv -- python3 $REPO/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
+  echo "pmc $c done"
+done
+find $OUT -name "*.csv" | head -20
