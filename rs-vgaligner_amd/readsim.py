@@ -50,6 +50,7 @@ class SimRead:
     seq: str
     path: str
     offset: int
+    template_len: int = 0  # bases of the source path the read was drawn from (before errors)
 
 
 def _mutate(tpl: np.ndarray, rng: np.random.Generator, sub: float, ins: float, dele: float) -> bytes:
@@ -119,7 +120,7 @@ def simulate_reads(gfa_path: str, n_reads: int, read_len: int, sub: float, ins: 
             seq = tpl.tobytes().decode()
         else:
             seq = _mutate(tpl, rng, sub, ins, dele).decode()
-        reads.append(SimRead(f"read{r}", seq, name, off))
+        reads.append(SimRead(f"read{r}", seq, name, off, L))
     return reads
 
 
@@ -129,6 +130,33 @@ def config2_reads(gfa_path: str, n_reads: int = 1000) -> List[SimRead]:
 
 def config3_reads(gfa_path: str, n_reads: int = 10000, read_len: int = 10000) -> List[SimRead]:
     return simulate_reads(gfa_path, n_reads, read_len, 0.03, 0.03, 0.04, seed=77)
+
+
+def truth_gaf(gfa_path: str, reads: List[SimRead]) -> str:
+    """The GAF a perfect aligner would write for simulated reads, as far as the node path goes: one record per read
+    whose path field lists the nodes the read's template [offset, offset + template length) overlaps on its source
+    path (what `vg sim -a` + `vg convert --gam-to-gaf` provide in the reference's experiments, Snakefile:32-40).
+    The template length is not stored; it is bounded by the read's own source window: reads are cut from the path
+    at `offset` with the requested length before errors are applied, so the window is recomputed from the path."""
+    segs, paths = parse_gfa_paths(gfa_path)
+    by_name = {name: steps for name, steps in paths}
+    out = []
+    for r in reads:
+        steps = by_name[r.path]
+        lens = [len(segs[n]) for n, _ in steps]
+        total = sum(lens)
+        tpl = min(getattr(r, "template_len", 0) or len(r.seq), total - r.offset)
+        lo, hi = r.offset, r.offset + tpl
+        pos, nodes = 0, []
+        for (nid, rev), ln in zip(steps, lens):
+            if pos < hi and pos + ln > lo:
+                nodes.append(("<" if rev else ">") + str(nid))
+            pos += ln
+            if pos >= hi:
+                break
+        out.append("\t".join([r.name, str(len(r.seq)), "0", str(len(r.seq)), "+", "".join(nodes), str(tpl), "0", str(tpl), "0",
+                              str(tpl), "255", "ta:Z:truth"]))
+    return "\n".join(out) + ("\n" if out else "")
 
 
 def write_fasta(reads: List[SimRead], path: str) -> None:
