@@ -10,7 +10,8 @@ out = "/tmp/vga_poa_marked.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-DPOA_MARKERS",
                        "-S", "--cuda-device-only", "-I", os.path.dirname(src), src, "-o", out], stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_Z11k_poa_dp_pkILi%sELb0" % nt))
+# the default instantiation: compile-time penalties, 4 columns per lane, 32-bit row state
+start = next(i for i, l in enumerate(lines) if l.startswith("_Z11k_poa_dp_pkILi%sELb0ELb1ELi4ELb0EE" % nt))
 end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
 region = "prologue"
 cnt = collections.OrderedDict()
@@ -30,3 +31,14 @@ for l in lines[start:end]:
         c["spill"] += 1
 for k, c in cnt.items():
     print("%-14s valu %4d (spill %3d)  salu %4d  lds %3d  vmem %3d" % (k, c["valu"], c["spill"], c["salu"], c["lds"], c["vmem"]))
+
+if len(sys.argv) > 2:  # list the spill instructions of one region
+    region = "prologue"
+    for l in lines[start:end]:
+        t = l.strip()
+        m = re.match(r"; MARK (\w+)", t)
+        if m:
+            region = m.group(1)
+            continue
+        if region == sys.argv[2] and (t.startswith("v_readlane") or t.startswith("v_writelane")):
+            print("   ", t)
