@@ -346,3 +346,31 @@ def test_batch_outlives_its_context(drb1, oracle):
     assert int(b2.align(b2.map()).aligned.sum()) == n1
     b2.close()
     c2.close()
+
+
+def test_two_contexts_driven_from_two_threads(drb1):
+    """one context per thread on the same device, concurrently: same records as a sequential run"""
+    import threading
+
+    p = pkg()
+    _, ix = drb1
+    seqs = [r.seq for r in p.readsim.simulate_reads(DRB1, 24, 1500, 0.03, 0.03, 0.04, seed=17)]
+    out = {}
+
+    def work(tag, n_rounds):
+        c = p.Context(0)
+        upload_oracle_index(c, ix)
+        b = c.batch(seqs)
+        for _ in range(n_rounds):
+            al = b.align(b.map())
+        out[tag] = (al.cigar, al.cs, al.path_handles.tolist(), al.best_score.tolist())
+        b.close()
+        c.close()
+
+    work("seq", 1)
+    th = [threading.Thread(target=work, args=(t, 3)) for t in ("a", "b")]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert out["a"] == out["seq"] and out["b"] == out["seq"]
