@@ -2511,7 +2511,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         {
             uint32_t mq = 0;
             double mw = 0;
-            for (uint64_t i = i0; i < i1; i++) { mq = std::max(mq, G[order[i]].qlen); mw = std::max(mw, estw[order[i]]); }
+            double sum_w = 0;
+            for (uint64_t i = i0; i < i1; i++) { mq = std::max(mq, G[order[i]].qlen); mw = std::max(mw, estw[order[i]]); sum_w += estw[order[i]]; }
+            const double mean_w = sum_w / (double)nb;
             const uint32_t lds_cols = poa_lds_cols(mq);
             // VGA_POA_KERNEL (testing): "unpacked" selects k_poa_dp_lds, "128" / "256" / "512" pin the workgroup size,
             // "full" keeps every column in LDS; VGA_POA_WINDOW=<power of two> pins the LDS column window
@@ -2552,6 +2554,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                     const size_t waves = std::min<size_t>(order.size() - i0 + in_flight_other, per_cu * (size_t)ctx->n_cu) * (size_t)(t / 64);
                     if (waves > best_waves) { best_waves = waves; nt = t; }
                 }
+                // narrow bands (one step of a 128-thread workgroup covers a typical row): the per-row set-up and the
+                // barriers dominate, and they are per wave -- config 5 (mean width 340): +6 % with 128 threads
+                if (mean_w <= 800.0) nt = 128;  // (the estimate is of a problem's widest rows: about twice its mean band)
                 const char *ent = getenv("VGA_POA_NT");
                 if (ent) nt = atoi(ent);
                 if (nt < 128 || nt > 512 || nt % 64) nt = 512;
@@ -2565,8 +2570,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             while (nt > 128 && lds_of(nt) > 160 * 1024 - 256) nt = packed ? nt - 64 : nt / 2;
             const size_t lds = lds_of(nt);
             if (tr.on)
-                fprintf(stderr, "[vga-trace] poa: launch %u problems, NT %d, %s, window %u of %u columns, widest estimate %.0f, LDS %zu B\n",
-                        nb, nt, h16 ? "16-bit rows" : "32-bit rows", hg_cols, lds_cols, mw, lds);
+                fprintf(stderr, "[vga-trace] poa: launch %u problems, NT %d, %s, window %u of %u columns, width estimate mean %.0f max %.0f, LDS %zu B\n",
+                        nb, nt, h16 ? "16-bit rows" : "32-bit rows", hg_cols, lds_cols, mean_w, mw, lds);
             (void)hipGetLastError();  // a launch failure below must be this launch's, not an older ignored status
 #define POA_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_sink.p, P, S.d_rows.p, pool_base,          \
                  W.d_next.p + slot, half_pool, S.d_outs.p, lds_cols
