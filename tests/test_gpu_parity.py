@@ -374,3 +374,36 @@ def test_two_contexts_driven_from_two_threads(drb1):
     for t in th:
         t.join()
     assert out["a"] == out["seq"] and out["b"] == out["seq"]
+
+
+def test_align_best_of_n_chains(oracle, ctx, drb1):
+    """align_best_n > 1 (src/align.rs:34-55): every read's first min(n, len) chains are aligned and the record with
+    the longest path_length wins (stable, None < Some).  Only chains that end on the maximal score are reported
+    (src/chain.rs:455-558), so several chains per read need ties: error-free reads made of the same piece two or three
+    times -- the copies cannot chain with each other (the target would have to go backwards) and score the same."""
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    p = pkg()
+    src = p.readsim.simulate_reads(DRB1, 6, 700, 0.0, 0.0, 0.0, seed=23)
+    seqs = [r.seq[:500] + r.seq[:500] for r in src] + [src[0].seq[:300] * 3, src[1].seq]
+    names = [f"dup{i}" for i in range(len(seqs))]
+    b = ctx.batch(seqs)
+    mo = b.map()
+    compare_map(oracle, ix, mo, seqs)
+    assert max(len(mo.chains_of(r)) for r in range(len(seqs))) >= 2, "the test needs reads with several chains"
+    for best_n in (1, 2, 5):
+        al = b.align(mo, best_n=best_n)
+        mp = oracle.default_map_params()
+        mp.align_best_n = best_n
+        _, ag, st = oracle.map_reads(ix, names, seqs, mp)
+        for r, ln in enumerate(ag.splitlines()):
+            f = ln.split("\t")
+            assert (f[5] != "*") == bool(al.aligned[r])
+            if f[5] == "*":
+                continue
+            hs = al.path_handles[int(al.path_off[r]):int(al.path_off[r + 1])].tolist()
+            assert "".join((">" if not (h & 1) else "<") + str(h >> 1) for h in hs) == f[5], f"best_n {best_n} read {r}: node path"
+            assert f[12] == "as:i:-30 " + al.cs[r] + ",cg:Z:" + al.cigar[r], f"best_n {best_n} read {r}: cs / CIGAR"
+            assert (int(f[6]), int(f[7]), int(f[8]), int(f[10])) == (
+                int(al.path_length[r]), int(al.path_start[r]), int(al.path_end[r]), int(al.block_length[r]))
+        assert al.poa_cells == st["poa_cells"], f"best_n {best_n}: the same chains were aligned"
