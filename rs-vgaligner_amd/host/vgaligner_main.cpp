@@ -10,17 +10,24 @@ using namespace vgh;
 
 namespace {
 
-struct Flag { const char *shortf, *longf; bool takes_value; };
+// short flag, long flag (src/subcommands/cli.yml), takes a value, key (the argument's name in cli.yml)
+struct Flag { const char *shortf, *longf; bool takes_value; const char *key; };
 
-const Flag INDEX_FLAGS[] = {{"-i", "--input", true}, {"-o", "--out-prefix", true}, {"-k", "--kmer-length", true},
-                            {"-e", "--max-furcations", true}, {"-m", "--max-degree", true}, {"-r", "--sampling-rate", true},
-                            {"-g", "--generate-mappings", false}, {"-p", "--mappings-path", true}, {"-t", "--n-threads", true}};
-const Flag MAP_FLAGS[] = {{"-i", "--index", true}, {"-f", "--input-file", true}, {"-o", "--out-prefix", true},
-                          {"-g", "--max-gap-length", true}, {"-r", "--max-mismatch-rate", true}, {"-c", "--chain-overlap-max", true},
-                          {"-a", "--chain-min-anchors", true}, {"-b", "--align-best-n", true}, {"-C", "--write-console", false},
-                          {"-D", "--also-align", false}, {"-t", "--n-threads", true}, {"-v", "--also-validate", false},
-                          {"-G", "--graph", true}, {"-P", "--validation-path", true}, {"-p", "--poa-aligner", true},
-                          {"-d", "--device", true}};
+const Flag INDEX_FLAGS[] = {{"-i", "--input", true, "input"}, {"-o", "--output", true, "out-prefix"}, {"-k", "--kmer-length", true, "kmer-length"},
+                            {"-e", "--max-furcations", true, "max-furcations"}, {"-m", "--max-degree", true, "max-degree"},
+                            {"-r", "--sampling-rate", true, "sampling-rate"}, {"-g", "--generate-mappings", false, "generate-mappings"},
+                            {"-p", "--mappings-path", true, "mappings-path"}, {"-t", "--threads", true, "n-threads"},
+                            // the argument names, accepted as long flags too
+                            {"", "--out-prefix", true, "out-prefix"}, {"", "--n-threads", true, "n-threads"}};
+const Flag MAP_FLAGS[] = {{"-i", "--index", true, "index"}, {"-f", "--input-file", true, "input-file"}, {"-o", "--out", true, "out-prefix"},
+                          {"-g", "--max-gap-length", true, "max-gap-length"}, {"-r", "--max-mismatch-rate", true, "max-mismatch-rate"},
+                          {"-c", "--chain-overlap-max", true, "chain-overlap-max"}, {"-a", "--chain-min-anchors", true, "chain-min-anchors"},
+                          {"-b", "--align-best-n", true, "align-best-n"}, {"-C", "--write-console", false, "write-console"},
+                          {"-D", "--also-align", false, "also-align"}, {"-t", "--threads", true, "n-threads"},
+                          {"-v", "--also-validate", false, "also-validate"}, {"-G", "--graph", true, "graph"},
+                          {"-P", "--validation-path", true, "validation-path"}, {"-p", "--poa-aligner", true, "poa-aligner"},
+                          {"", "--out-prefix", true, "out-prefix"}, {"", "--n-threads", true, "n-threads"},
+                          {"-d", "--device", true, "device"}};  // --device: which GPU (not in the reference)
 
 template <size_t N>
 std::map<std::string, std::string> parse(const Flag (&flags)[N], int argc, char **argv, int first)
@@ -29,12 +36,12 @@ std::map<std::string, std::string> parse(const Flag (&flags)[N], int argc, char 
     for (int i = first; i < argc; i++) {
         const Flag *f = nullptr;
         for (const Flag &c : flags)
-            if (!strcmp(argv[i], c.shortf) || !strcmp(argv[i], c.longf)) f = &c;
+            if ((c.shortf[0] && !strcmp(argv[i], c.shortf)) || !strcmp(argv[i], c.longf)) { f = &c; break; }
         if (!f) throw Error(std::string("unknown argument ") + argv[i]);
         if (f->takes_value) {
             if (i + 1 >= argc) throw Error(std::string("missing value for ") + argv[i]);
-            m[f->longf + 2] = argv[++i];
-        } else m[f->longf + 2] = "1";
+            m[f->key] = argv[++i];
+        } else m[f->key] = "1";
     }
     return m;
 }
