@@ -54,10 +54,18 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the library has no CPU path)")
+    # VGA_BENCH_REHEARSAL=1 (testing the N > 1 code path on a box with fewer GPUs than ranks): ranks share the GPUs that
+    # exist and the timing reduction runs over gloo.  Never set by the driver; the numbers of such a run mean nothing.
+    rehearsal = os.environ.get("VGA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     # host threads of the library (subgraph extraction, CIGAR strings): share the node's cores between the ranks
     if world > 1 and "VGA_HOST_THREADS" not in os.environ:
@@ -115,7 +123,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     elapsed, aligned_all, reads_all = pkg.sharding.reduce_timing(elapsed, last["aligned"], last["n_reads"], world,
-                                                                 device="cuda" if world > 1 else None)
+                                                                 device="cuda" if world > 1 and not rehearsal else None)
 
     if rank != 0:
         if world > 1:
