@@ -1347,7 +1347,12 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
             const int jw0 = bal + c0 + 64 * CPT * wv, jw1 = jw0 + 64 * CPT - 1;
             const bool lp = jw0 < beg;
             const bool rp = jw1 > end || jw1 > pend;
-            const bool fastw = single && q_plain && wave_act && (lp ? beg : jw0) > pbeg && (!rp || (sp_near && end <= pend + 1));
+            //  lq  the wave's first active column is not right of `pbeg` (the band did not move right, or moved left):
+            //      words left of `pbeg` are replaced by (NEG, g = 0) and M is forced to NEG where column j-1 lies left of
+            //      `pbeg`, exactly what the lean path computes for such cells.  LDS predecessors only (the HBM row starts
+            //      at pbeg), 32-bit row state only.
+            const bool lq = (lp ? beg : jw0) <= pbeg;
+            const bool fastw = single && q_plain && wave_act && (!lq || (sp_near && !H16)) && (!rp || (sp_near && end <= pend + 1));
             const int base1 = e1 * j0, base2 = e2 * j0;  // the max-plus scan runs on lane-relative values in the fast path
             if constexpr (STAMP) tacc[7] += (wave_act ? (1ull << 42) : 0ull) + (fastw ? 1ull : 0ull) + ((fastw && (lp || rp)) ? (1ull << 21) : 0ull);
         POA_MARK("p1_fast");
@@ -1477,13 +1482,20 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
 #pragma unroll
                             for (int k = 0; k < CPT; k++) wj[k] = j0 + k > pend ? (int)((uint32_t)POA_NEG << 8) : wj[k];
                         }
+                        if (lq) {
+#pragma unroll
+                            for (int k = 0; k < CPT; k++) wj[k] = j0 + k < pbeg ? (int)((uint32_t)POA_NEG << 8) : wj[k];
+                        }
                     }
                     const uint32_t eqb = qn >> gsh;
 #pragma unroll
                     for (int k = 0; k < CPT; k++) {
                         const int hj = wj[k] >> 8;
                         const int g1 = wj[k] & g1mask, g2 = (int)__builtin_amdgcn_ubfe((uint32_t)wj[k], (uint32_t)g1bits, (uint32_t)g2w);
-                        const int m = (hprev + sc_ne) + (int)((eqb >> (4 * k)) & 1u) * sc_mm;
+                        int m = (hprev + sc_ne) + (int)((eqb >> (4 * k)) & 1u) * sc_mm;
+                        if constexpr (EDGE) {
+                            if (lq) m = j0 + k - 1 < pbeg ? POA_NEG : m;
+                        }
                         const int ev1 = hj - g1, ev2 = hj - g2;
                         const int me = m > ev1 ? m : ev1;
                         const int h = me > ev2 ? me : ev2;
@@ -1512,7 +1524,7 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
                     agg1 = ag1 + base1;
                     agg2 = ag2 + base2;
                 };
-                if (__builtin_expect(lp || rp, 0)) phase1(std::true_type{});
+                if (__builtin_expect(lp || rp || lq, 0)) phase1(std::true_type{});
                 else phase1(std::false_type{});
               }
         POA_MARK("p1_lean");
