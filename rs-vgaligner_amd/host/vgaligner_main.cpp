@@ -92,7 +92,11 @@ int map_main(int argc, char **argv)
     o.also_align = m.count("also-align") > 0;
     o.poa_aligner = need(m, "poa-aligner");  // cli.yml:169-175: required
     o.device = std::stoi(opt(m, "device", "0"));
-    if (m.count("also-validate")) fprintf(stderr, "[vgaligner] --also-validate is not supported by this build (debug aid)\n");
+    o.also_validate = m.count("also-validate") > 0;
+    if (o.also_validate) {
+        if (!o.also_align) fprintf(stderr, "[vgaligner] --also-validate has no effect without --also-align (map.rs:150-186)\n");
+        o.validation_path = need(m, "validation-path");  // map.rs:201 unwraps it
+    }
     if (o.also_align && !m.count("graph")) throw Error("--also-align needs --graph (the reference unwraps it, map.rs:157)");
     bool exact = idx.size() >= 4 && idx.compare(idx.size() - 4, 4, ".idx") == 0;
     Index ix = Index::load(exact ? idx : idx + ".idx");

@@ -97,6 +97,8 @@ std::vector<QuerySequence> read_seqs_from_file(const std::string &filename);
 std::string gaf_placeholder(const QuerySequence &q);
 std::string gaf_from_chain(const Index &ix, const QuerySequence &q, const vga_map_result *m, uint64_t read, uint64_t chain);
 std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a, uint64_t read);
+// ValidationRecord::from_graph_and_alignment + to_string (src/validate.rs:36-102) from one alignments-GAF line
+std::string validation_record(const Index &ix, const std::string &gaf_line, const std::vector<QuerySequence> &reads);
 
 // ---- map_reads --------------------------------------------------------------------------------
 struct MapOptions {
@@ -111,10 +113,12 @@ struct MapOptions {
     uint64_t align_best_n = 1;           // -b
     std::string poa_aligner = "abpoa";   // -p
     int device = 0;
+    bool also_validate = false;          // -v: write validation records (src/validate.rs:18-102, map.rs:186-208)
+    std::string validation_path;         // -P
 };
 
 struct MapOutput {
-    std::string chains_gaf, alignments_gaf;
+    std::string chains_gaf, alignments_gaf, validation;
     uint64_t n_reads = 0, n_aligned = 0, n_anchors = 0, poa_cells = 0;
     double ms_map = 0, ms_align = 0;
 };

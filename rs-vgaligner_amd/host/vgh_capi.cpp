@@ -75,6 +75,26 @@ int vgh_map_reads(vga_ctx *ctx, void *h, uint64_t n, const char *const *names, c
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 
+// validation records (src/validate.rs:36-102, 127-145) of a whole alignments GAF; *out is malloc'd
+int vgh_validation_records(void *h, const char *alignments_gaf, uint64_t n, const char *const *names, const char *const *seqs, char **out)
+{
+    try {
+        std::vector<QuerySequence> in(n);
+        for (uint64_t i = 0; i < n; i++) in[i] = {names[i], seqs[i]};
+        const std::string g = alignments_gaf;
+        std::string res;
+        size_t p0 = 0;
+        while (p0 < g.size()) {
+            size_t p1 = g.find('\n', p0);
+            if (p1 == std::string::npos) p1 = g.size();
+            res += validation_record(((IndexBox *)h)->ix, g.substr(p0, p1 - p0), in);
+            p0 = p1 + 1;
+        }
+        *out = dup_str(res);
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
 // read_seqs_from_file: returns the number of reads or -1; names/seqs are malloc'd arrays of malloc'd strings
 int64_t vgh_read_seqs_from_file(const char *path, char ***names, char ***seqs)
 {

@@ -88,6 +88,58 @@ std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a
            "\t255\tas:i:-30 " + (a->cs + a->cs_off[r]) + ",cg:Z:" + (a->cigar + a->cigar_off[r]) + "\n";
 }
 
+// src/validate.rs:36-102.  The record is derived from the GAF record alone, as in the reference: read name, the last
+// comma-separated piece of the notes (cg:Z:<CIGAR>), the sequence of the FIRST read with that name (validate.rs:133-136),
+// the node ids of the path (both orientations parse to the bare id, validate.rs:104-111) and their sequences --
+// reverse-complemented when the last id is smaller than the first (validate.rs:50-53,113-124).  Debug formatting of
+// Vec<u64> / Vec<String>: [1, 2] and ["AC", "G"].
+std::string validation_record(const Index &ix, const std::string &gaf_line, const std::vector<QuerySequence> &reads)
+{
+    std::vector<std::string> f;
+    size_t a = 0;
+    std::string ln = gaf_line;
+    if (!ln.empty() && ln.back() == '\n') ln.pop_back();
+    for (;;) {
+        size_t b = ln.find('\t', a);
+        f.push_back(ln.substr(a, b == std::string::npos ? std::string::npos : b - a));
+        if (b == std::string::npos) break;
+        a = b + 1;
+    }
+    if (f.size() < 13) throw Error("validation: malformed GAF record");
+    const std::string &name = f[0], &path = f[5];
+    const QuerySequence *read = nullptr;
+    for (const QuerySequence &q : reads)
+        if (q.name == name) { read = &q; break; }
+    if (!read) throw Error("validation: no read named " + name);  // the reference unwraps
+    if (path == "*") return name + "\nNOT ALIGNED\n" + read->seq + "\n[]\n[]\n\n";
+    std::vector<uint64_t> ids;
+    for (size_t i = 0; i < path.size(); i++)
+        if ((path[i] == '>' || path[i] == '<') && i + 1 < path.size() && isdigit((unsigned char)path[i + 1])) {
+            uint64_t v = 0;
+            size_t j = i + 1;
+            while (j < path.size() && isdigit((unsigned char)path[j])) v = v * 10 + (uint64_t)(path[j++] - '0');
+            ids.push_back(v);
+            i = j - 1;
+        }
+    const bool rev = ids.size() >= 2 && ids.back() < ids.front();
+    const std::string &notes = f[12];
+    const size_t comma = notes.rfind(',');
+    std::string out = name + "\n" + (comma == std::string::npos ? notes : notes.substr(comma + 1)) + "\n" + read->seq + "\n[";
+    for (size_t i = 0; i < ids.size(); i++) out += (i ? ", " : "") + std::to_string(ids[i]);
+    out += "]\n[";
+    for (size_t i = 0; i < ids.size(); i++) {
+        if (ids[i] == 0 || ids[i] > ix.n_nodes) throw Error("validation: node " + std::to_string(ids[i]) + " is not in the graph");
+        std::string sq = ix.seq_fwd.substr(ix.node_ref[ids[i] - 1].seq_idx, ix.node_ref[ids[i]].seq_idx - ix.node_ref[ids[i] - 1].seq_idx);
+        if (rev) {  // graph.sequence(Handle::pack(id, true)): reverse complement, anything but ACGT kept
+            std::string rc(sq.rbegin(), sq.rend());
+            for (char &c : rc) c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c == 'a' ? 't' : c == 'c' ? 'g' : c == 'g' ? 'c' : c == 't' ? 'a' : c;
+            sq = rc;
+        }
+        out += std::string(i ? ", " : "") + "\"" + sq + "\"";
+    }
+    return out + "]\n\n";
+}
+
 static void write_file(const std::string &name, const std::string &body)
 {
     std::ofstream o(name, std::ios::binary);
@@ -141,6 +193,15 @@ MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequen
         }
         // map.rs:174-178: a prefix ending in .gaf makes the alignments overwrite the chains file
         if (!out_prefix.empty()) write_file(same_file ? out_prefix : out_prefix + "-alignments.gaf", out.alignments_gaf);
+        if (opt.also_validate) {  // map.rs:186-208
+            size_t p0 = 0;
+            while (p0 < out.alignments_gaf.size()) {
+                const size_t p1 = out.alignments_gaf.find('\n', p0);
+                out.validation += validation_record(ix, out.alignments_gaf.substr(p0, p1 - p0), inputs);
+                p0 = p1 + 1;
+            }
+            if (!opt.validation_path.empty()) write_file(opt.validation_path, out.validation);
+        }
         vga_align_result_free(a);
     }
     vga_map_result_free(m);

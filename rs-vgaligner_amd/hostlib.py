@@ -36,6 +36,7 @@ def load_library():
     L.vgh_index_upload.argtypes = [vp, vp]
     L.vgh_map_reads.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint64, C.c_uint64,
                                 C.c_int, C.c_uint64, C.c_char_p, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.vgh_validation_records.argtypes = [vp, C.c_char_p, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(vp)]
     L.vgh_read_seqs_from_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_char_p))]
     L.vgh_read_seqs_from_file.restype = C.c_int64
     L.vgh_free.argtypes = [vp]
@@ -108,6 +109,18 @@ class HostIndex:
         self.L.vgh_free(cg)
         self.L.vgh_free(ag)
         return c, a, int(na.value)
+
+    def validation_records(self, alignments_gaf: str, names: Sequence[str], seqs: Sequence[str]) -> str:
+        """create_validation_records + to_string (src/validate.rs:36-145) for every record of an alignments GAF"""
+        n = len(seqs)
+        nm = (C.c_char_p * n)(*[s.encode() for s in names])
+        sq = (C.c_char_p * n)(*[s.encode() for s in seqs])
+        out = C.c_void_p()
+        if self.L.vgh_validation_records(self.h, alignments_gaf.encode(), n, nm, sq, C.byref(out)) != 0:
+            raise HostError(self.L.vgh_last_error().decode())
+        s = C.string_at(out).decode()
+        self.L.vgh_free(out)
+        return s
 
     def close(self):
         if self.h:

@@ -85,6 +85,13 @@ def test_cli_end_to_end_reproduces_golden_gaf(tmp_path):
     p = run(["map", "--index", os.path.join(d, "drb1.idx"), "--input-file", fq, "--poa-aligner", "abpoa", "--also-align", "--graph", gfa,
              "--out", os.path.join(d, "o"), "--write-console", "--max-gap-length", "1000", "--chain-min-anchors", "3", "--align-best-n", "1"], d)
     w = want["drb1_600bp_ont"]
+    # --also-validate --validation-path (src/map.rs:186-208): one record per alignment
+    run(["map", "-i", os.path.join(d, "drb1.idx"), "-f", fq, "-p", "abpoa", "-D", "-G", gfa, "-o", os.path.join(d, "v"), "-v", "-P",
+         os.path.join(d, "val.txt")], d)
+    hi = pkg().HostIndex.build_from_gfa(gfa, k)
+    assert open(os.path.join(d, "val.txt")).read() == hi.validation_records(w["alignments_gaf"], [n for n, _ in reads], [s for _, s in reads])
+    p2 = run(["map", "-i", os.path.join(d, "drb1.idx"), "-f", fq, "-p", "abpoa", "-D", "-G", gfa, "-o", os.path.join(d, "v"), "-v"], d, ok=False)
+    assert "validation-path" in p2.stderr
     assert open(os.path.join(d, "o-chains.gaf")).read() == w["chains_gaf"]
     assert open(os.path.join(d, "o-alignments.gaf")).read() == w["alignments_gaf"] == p.stdout
     # rspoa is the reference's other backend: not built here, refused by name

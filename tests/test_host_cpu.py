@@ -121,3 +121,39 @@ def test_host_reader_multiline_fasta(tmp_path):
     f = tmp_path / "m.fa"
     f.write_text(">a b\nACGT\nTTTT\n\nGG\n>c\nAA\n")
     assert pkg().hostlib.read_seqs_from_file(str(f)) == [("a b", "ACGT"), ("a b1", "TTTT"), ("a b2", "GG"), ("c", "AA")]
+
+
+def test_validation_records(tmp_path):
+    """src/validate.rs: parse_nodes_from_path_matching (tests at validate.rs:227-240: ">1<2>3" -> [1, 2, 3],
+    ">10<20" -> [10, 20], "*" -> []) and ValidationRecord::to_string, through the C++ host"""
+    import json
+
+    p = pkg()
+    gfa = tmp_path / "g.gfa"
+    gfa.write_text("H\tVN:Z:1.0\n" + "".join("S\t%d\t%s\n" % (i + 1, s) for i, s in enumerate(["AAC", "ACG", "T"] + ["G"] * 17))
+                   + "".join("L\t%d\t+\t%d\t+\t0M\n" % (i, i + 1) for i in range(1, 20)))
+    hi = p.HostIndex.build_from_gfa(str(gfa), 3)
+    rec = lambda path, notes="as:i:-30 cs:Z::3,cg:Z:3M": "r\t3\t0\t3\t+\t%s\t3\t0\t3\t0\t3\t255\t%s\n" % (path, notes)
+    got = hi.validation_records(rec(">1<2>3"), ["r", "r"], ["AAC", "TTT"])
+    assert got == 'r\ncg:Z:3M\nAAC\n[1, 2, 3]\n["AAC", "ACG", "T"]\n\n'  # the first read named r; '<' parses to the bare id
+    assert hi.validation_records(rec(">10<20"), ["r"], ["AAC"]).splitlines()[3] == "[10, 20]"
+    # last id < first id: the sequences are reverse-complemented (validate.rs:50-53,113-124)
+    assert hi.validation_records(rec("<2<1"), ["r"], ["AAC"]).splitlines()[3:5] == ["[2, 1]", '["CGT", "GTT"]']
+    assert hi.validation_records("r\t3\t*\t*\t*\t*\t*\t*\t*\t*\t*\t0\t*\n", ["r"], ["AAC"]) == "r\nNOT ALIGNED\nAAC\n[]\n[]\n\n"
+    with pytest.raises(p.hostlib.HostError):  # the reference unwraps the read lookup
+        hi.validation_records(rec(">1"), ["x"], ["AAC"])
+    # the golden DRB1 alignments: one record per line, the node sequences spell the path
+    want = json.load(open(os.path.join(os.path.dirname(DATA), "hot_path.json")))["drb1_600bp_ont"]
+    drb1 = p.HostIndex.build_from_gfa(os.path.join(DATA, "DRB1-3123.gfa"), 11)
+    arr = drb1.arrays()
+    lines = want["alignments_gaf"].splitlines()
+    names = [ln.split("\t")[0] for ln in lines]
+    out = drb1.validation_records(want["alignments_gaf"], names, ["ACGT"] * len(names)).split("\n\n")
+    assert len(out) == len(lines) + 1 and out[-1] == ""
+    for ln, r in zip(lines, out):
+        f, v = ln.split("\t"), r.split("\n")
+        ids = [int(x) for x in f[5].replace(">", " ").split()]
+        st = arr["node_seq_idx"]
+        assert v[0] == f[0] and v[1] == "cg:Z:" + f[12].split(",cg:Z:")[1] and v[2] == "ACGT"
+        assert v[3] == "[" + ", ".join(map(str, ids)) + "]"
+        assert v[4] == "[" + ", ".join('"%s"' % arr["seq_fwd"][int(st[i - 1]):int(st[i])].decode() for i in ids) + "]"
