@@ -900,7 +900,10 @@ __device__ __forceinline__ int pk_hi(int a) { return a >> 16; }
 // predecessors' maximum) plus a byte plane of the gap deltas: 3 B per column.  Scores that come within 2 768 of the int16
 // range stop the problem with POA_ST_RANGE and the host re-runs it with 32-bit words.
 template <int NT, bool STAMP = false, bool DEF = false, int CPT = 4, bool H16 = false>
-__global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 7)) void k_poa_dp_pk(
+// Six waves per SIMD (80 VGPRs), not the seven that 21.6 KB of LDS per workgroup would allow: measured same-box
+// (tests/prof_lib_ab.sh), 7 -> 6 / 5 / 4 waves per SIMD are all +1.5 % on config 3 (+2 % on configs 4 and 5) and equal among
+// themselves -- the kernel is bound by VALU issue, and the allocator does better with eight more registers.
+__global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 6)) void k_poa_dp_pk(
     const poa_prob *__restrict__ probs, const char *__restrict__ queries, const uint4 *__restrict__ node_tab,
     const uint32_t *__restrict__ seq32, const uint32_t *__restrict__ preds, const uint32_t *__restrict__ sink_preds,
     poa_dev_params P, poa_row *rows, uint8_t *pool_arg, unsigned long long *pool_next_arg, uint64_t pool_size_arg,
@@ -2562,7 +2565,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 auto by_lds = [&](int t) { return std::max<size_t>(1, (160 * 1024) / (poa_pk_lds_bytes(hg_cols, lds_cols, t, h16) + 256)); };
                 size_t best_waves = 0;
                 for (int t = 128; t <= 512; t += 64) {
-                    const size_t per_cu = std::min<size_t>(by_lds(t), (size_t)((cpt == 8 ? 20 : 28) / (t / 64)));
+                    const size_t per_cu = std::min<size_t>(by_lds(t), (size_t)((cpt == 8 ? 20 : 24) / (t / 64)));
                     const size_t waves = std::min<size_t>(order.size() - i0 + in_flight_other, per_cu * (size_t)ctx->n_cu) * (size_t)(t / 64);
                     if (waves > best_waves) { best_waves = waves; nt = t; }
                 }
