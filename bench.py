@@ -217,6 +217,8 @@ def main():
         "per_step": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last.items() if k != "kernels"},
         "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in kern.items()},
         "kernels_busy_ms_per_step": {k: round(v["busy_ms"] / args.steps, 3) for k, v in kern.items()},
+        # algorithmic bytes (per kernel) over the kernel's busy time
+        "kernels_algorithmic_gbs": {k: round(v["bytes"] / (v["busy_ms"] * 1e-3) / 1e9, 1) for k, v in kern.items() if v["busy_ms"] > 0 and v["bytes"]},
         "gen_s": round(t_gen, 1),
     }
     print(json.dumps(out))

@@ -2437,6 +2437,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
 
     bool packed_all = true;  // value rows are 4 B per cell with the packed kernel, 6 B otherwise (byte model)
     bool h16_all = true;     // ... and 3 B with 16-bit row state
+    bool any_fused = false;  // the DP kernel walked the alignments back itself
     int t_total = vga_timer_begin(ctx, "poa_total", 0);
     struct sub_t { uint64_t i0, i1; double raw_est; int slot; int oset; bool use32 = false; bool arena = false; };
     hipError_t launch_err = hipSuccess;
@@ -2547,6 +2548,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             h16_all = h16_all && h16;
             sub_h16 = h16;
             sub_fused = packed && tb_fused && !getenv("VGA_POA_STAMPS");
+            any_fused = any_fused || sub_fused;
             // LDS column window (packed kernel): 4096 columns keep almost every row of a 10 kbp read resident (its widest
             // rows, a few per cent, take the HBM detour described in the kernel) and let seven workgroups share a CU
             // instead of three.  Queries that fit a smaller array anyway keep every column.
@@ -2883,8 +2885,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     // byte model of the DP kernel: graph bases + query + 1 direction byte per cell
     // + the value rows kept in HBM (4 B per cell packed, 6 B otherwise), written once and read back at least once
     for (auto &a : ctx->last_times) {
-        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + (h16_all ? 6 : (packed_all ? 8 : 12)) * all_vcells;
-        if (a.name == "poa_traceback") a.bytes = 6 * all_ops;
+        // (the traceback's 6 bytes per alignment column belong to whichever kernel walked: the DP kernel when fused)
+        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + (h16_all ? 6 : (packed_all ? 8 : 12)) * all_vcells + (any_fused ? 6 * all_ops : 0);
+        if (a.name == "poa_traceback") a.bytes = any_fused ? 0 : 6 * all_ops;
     }
     tm.ms_dp = vga_timer_sum(ctx, "poa_band_dp");
     tm.ms_tb = vga_timer_sum(ctx, "poa_traceback");
