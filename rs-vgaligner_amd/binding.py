@@ -288,6 +288,28 @@ class Batch:
         self.ctx._check(L.vga_align_batch(self.h, chains._ptr, best_n, C.byref(p), C.byref(out)))
         return AlignOut(L, out)
 
+    def map_raw(self, map_params: Optional[MapParams] = None) -> dict:
+        """One map-only pass (anchors + chains; BASELINE config #2) without numpy conversion.  Counters only."""
+        L = self.ctx.L
+        mp = map_params
+        if mp is None:
+            mp = default_map_params()
+            mp.emit_dp = 0  # the chains GAF reads coordinates and chain membership only
+        m = _P(MapResult)()
+        self.ctx._check(L.vga_map_batch(self.h, C.byref(mp), C.byref(m)))
+        try:
+            q = m.contents
+            R = int(q.n_reads)
+            ph = np.ctypeslib.as_array(q.chain_placeholder, shape=(int(q.n_chains),)) if int(q.n_chains) else np.zeros(0, np.uint8)
+            co = np.ctypeslib.as_array(q.chain_off, shape=(R + 1,)) if R else np.zeros(1, np.uint64)
+            # a read is mapped when its first chain is a real one
+            mapped = int((ph[co[:-1].astype(np.int64)] == 0).sum()) if R else 0
+            return dict(n_reads=R, aligned=mapped, n_anchors=int(q.n_anchors), n_hits=int(q.n_hits), n_chains=int(q.n_chains),
+                        ms_map=float(q.ms_total), ms_probe=float(q.ms_probe), ms_sort=float(q.ms_sort), ms_chain=float(q.ms_chain),
+                        kernels=self.ctx.kernel_times())
+        finally:
+            L.vga_map_result_free(m)
+
     def map_align_raw(self, map_params: Optional[MapParams] = None, best_n: int = 1,
                       poa_params: Optional[PoaParams] = None) -> dict:
         """One pass of the whole hot path without converting the results to numpy (bench.py's timed step).
