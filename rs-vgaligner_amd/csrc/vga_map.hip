@@ -325,6 +325,169 @@ __global__ __launch_bounds__(VGA_WAVE) void k_chain(
     if (lane == 0) { chain_cnt[r] = nch; chain_words[r] = wpos; }
 }
 
+// K3, current form.  Same recurrence, window and tie rule as k_chain (kept below the name k_chain for cross-checks,
+// VGA_MAP_CHAIN=old); what changes is the latency of one step of the serial chain, ~4 300 cycles there:
+//   * the argmax over the window is a DPP max-reduction of the f64 scores (18 VALU instructions, result in lane 63)
+//     instead of a 6-stage butterfly of 18 ds_bpermute; the winning j follows from the ballot of the lanes that hold
+//     the maximum: lane l keeps the most recent anchor j = l (mod 64), so the largest j is the set lane cyclically
+//     nearest below (i - 1) & 63 -- a rotate and a count-leading-zeros on the scalar unit;
+//   * the gap-cost table sits in LDS (shared by the four reads of a workgroup) instead of a per-lane gather from HBM;
+//   * anchors are loaded 64 at a time (lane l holds anchor base + l) and read per step with v_readlane, and f(i) /
+//     predecessors go out 64 at a time, coalesced, with the predecessor ids gathered in parallel -- no global load or
+//     store on the per-anchor chain.
+// One wavefront per read, four reads per workgroup.
+__device__ __forceinline__ double vga_wave_max_f64_to_lane63(double v)
+{
+    const int ident_lo = (int)0xffffffffu, ident_hi = (int)0xffefffffu;  // -f64::MAX
+#define VGA_STAGE(ctrl, rmask)                                                                                    \
+    {                                                                                                             \
+        const int lo = __builtin_amdgcn_update_dpp(ident_lo, __double2loint(v), ctrl, rmask, 0xf, false);         \
+        const int hi = __builtin_amdgcn_update_dpp(ident_hi, __double2hiint(v), ctrl, rmask, 0xf, false);         \
+        const double t = __hiloint2double(hi, lo);                                                                \
+        v = t > v ? t : v;                                                                                        \
+    }
+    VGA_STAGE(0x111, 0xf)  // row_shr:1
+    VGA_STAGE(0x112, 0xf)  // row_shr:2
+    VGA_STAGE(0x114, 0xf)  // row_shr:4
+    VGA_STAGE(0x118, 0xf)  // row_shr:8
+    VGA_STAGE(0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+    VGA_STAGE(0x143, 0xc)  // row_bcast:31 -> rows 2, 3
+#undef VGA_STAGE
+    return v;
+}
+
+template <bool GAP_LDS>
+__global__ __launch_bounds__(256) void k_chain4(
+    uint32_t R, const uint64_t *__restrict__ anchor_off, const uint32_t *__restrict__ s_id, const uint32_t *__restrict__ s_qb,
+    const uint32_t *__restrict__ s_tb, const uint32_t *__restrict__ s_te, uint32_t k, uint32_t bandwidth,
+    uint64_t max_gap, uint32_t min_anchors, const double *__restrict__ gap_cost, double *__restrict__ f_out,
+    int32_t *__restrict__ pred_id_out, int32_t *pred_pos, double *__restrict__ curr_max_out,
+    uint32_t *__restrict__ chain_buf, uint32_t *__restrict__ chain_cnt, uint32_t *__restrict__ chain_words)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_gap[];
+    if constexpr (GAP_LDS) {
+        for (uint64_t g = threadIdx.x; g <= max_gap; g += blockDim.x) s_gap[g] = gap_cost[g];
+        __syncthreads();
+    }
+    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t a0 = anchor_off[r];
+    const uint32_t A = (uint32_t)(anchor_off[r + 1] - a0);
+    const double kd = (double)k;
+    const double NEGMAX = -1.7976931348623157e308;  // -f64::MAX
+    double curr_max = 0.0;
+
+    double f_l = 0.0;
+    uint32_t qb_l = 0, tb_l = 0, te_l = 0;
+    int j_l = -1, pj_l = -1;
+
+    for (uint32_t base = 0; base < A; base += 64) {
+        const uint32_t nb = A - base < 64 ? A - base : 64;
+        uint32_t cq = 0, ct = 0, ce = 0;  // anchor base + lane
+        if (lane < nb) { cq = s_qb[a0 + base + lane]; ct = s_tb[a0 + base + lane]; ce = s_te[a0 + base + lane]; }
+        for (uint32_t ii = 0; ii < nb; ii++) {
+            const uint32_t i = base + ii;
+            const uint32_t qbi = (uint32_t)__builtin_amdgcn_readlane((int)cq, (int)ii);
+            const uint32_t tbi = (uint32_t)__builtin_amdgcn_readlane((int)ct, (int)ii);
+            const uint32_t tei = (uint32_t)__builtin_amdgcn_readlane((int)ce, (int)ii);
+            double p = NEGMAX;
+            int j = -1;
+            if (i > 0) {
+                const int min_j = (bandwidth > i) ? 0 : (int)(i - bandwidth);  // src/chain.rs:404-407
+                bool ok = false;
+                if (j_l >= min_j) {
+                    // score_anchor(a = j_l, b = i), src/chain.rs:274-368, all orientations Forward
+                    if (!(qb_l >= qbi || te_l >= tei)) {
+                        const uint64_t ql = (uint64_t)(qbi - qb_l);
+                        const uint64_t tbd = tbi > tb_l ? (uint64_t)(tbi - tb_l) : (uint64_t)(tb_l - tbi);
+                        const uint64_t ted = (uint64_t)(tei - te_l);
+                        const uint64_t tl = tbd < ted ? tbd : ted;
+                        const uint64_t g = ql > tl ? ql - tl : tl - ql;
+                        if (g <= max_gap) {
+                            const double gc = GAP_LDS ? s_gap[g] : gap_cost[g];
+                            uint64_t ml = ql < tl ? ql : tl;
+                            if ((uint64_t)k < ml) ml = k;
+                            double s = f_l + (double)ml;
+                            s = s - gc;
+                            s = s * 1000.0;
+                            s = round(s);
+                            s = s / 1000.0;
+                            s = s + 0.0;
+                            p = s;
+                            ok = true;
+                        }
+                    }
+                }
+                // the maximum, then the largest j among the lanes that hold it (src/chain.rs:417,430: the scan runs from
+                // i-1 downwards with a strict '>')
+                const double red = vga_wave_max_f64_to_lane63(p);
+                const double pmax = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(red), 63),
+                                                     __builtin_amdgcn_readlane(__double2loint(red), 63));
+                const uint64_t mask = __ballot(ok && p == pmax);
+                p = pmax;
+                if (mask) {
+                    const uint32_t sft = 63u - ((i - 1u) & 63u);  // lane (i-1) & 63 -> bit 63
+                    const uint64_t rot = sft ? ((mask << sft) | (mask >> (64u - sft))) : mask;
+                    const int d = __builtin_clzll(rot);  // 0 for the lane of anchor i-1
+                    j = (int)i - 1 - d;
+                } else p = NEGMAX;
+            }
+            double fi = kd;  // src/chain.rs:163: initial f(i) = k
+            int pj = -1;
+            if (p > fi) { fi = p; pj = j; }
+            if (p > curr_max) curr_max = p;
+            if (lane == ii) { f_l = fi; qb_l = cq; tb_l = ct; te_l = ce; j_l = (int)i; pj_l = pj; }
+        }
+        // lane l now holds f and the predecessor of anchor base + l
+        if (lane < nb) {
+            f_out[a0 + base + lane] = f_l;
+            pred_pos[a0 + base + lane] = pj_l;
+            pred_id_out[a0 + base + lane] = pj_l >= 0 ? (int32_t)s_id[a0 + pj_l] : -1;
+        }
+    }
+    if (lane == 0) curr_max_out[r] = curr_max;
+    __threadfence_block();
+
+    // ---- backtracking, src/chain.rs:455-558 (as in k_chain)
+    uint32_t *buf = chain_buf + 3 * a0 + 2 * (uint64_t)r;
+    volatile int32_t *vpred = pred_pos + a0;
+    const double *fr = f_out + a0;
+    uint32_t nch = 0, wpos = 0;
+    for (int top = (int)A; top > 0; top -= 64) {
+        const int i = top - 1 - (int)lane;
+        bool cand = false;
+        if (i >= 0) cand = vpred[i] >= 0 && fr[i] == curr_max;
+        uint64_t mask = __ballot(cand);
+        while (mask) {
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            int cur = top - 1 - l;
+            if (vpred[cur] < 0) continue;  // consumed by an earlier chain (src/chain.rs:469,478)
+            const uint32_t hdr = wpos++;
+            uint32_t len = 0;
+            int pnext;
+            while ((pnext = vpred[cur]) >= 0) {
+                if (lane == 0) { vpred[cur] = -1; buf[wpos] = (uint32_t)cur; }
+                __threadfence_block();
+                wpos++;
+                len++;
+                cur = pnext;
+            }
+            if (lane == 0) buf[wpos] = (uint32_t)cur;
+            wpos++;
+            len++;
+            if (len >= min_anchors) {
+                if (lane == 0) buf[hdr] = len;
+                nch++;
+            } else {
+                wpos = hdr;
+            }
+        }
+    }
+    if (lane == 0) { chain_cnt[r] = nch; chain_words[r] = wpos; }
+}
+
 // ------------------------------------------------------------------------------------------ host
 namespace {
 
@@ -509,9 +672,20 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
 
     // ---- K3: chain DP + backtracking
     int t4 = vga_timer_begin(ctx, "chain_dp", 16 * total + 12 * total);
-    hipLaunchKernelGGL(k_chain, dim3((unsigned)R), dim3(VGA_WAVE), 0, st, ws.anchor_off.p, perm, ws.s_qb.p, ws.s_tb.p, ws.s_te.p,
-                       ix.k, params->bandwidth, params->max_gap, params->chain_min_n_anchors, ws.gap_cost.p, ws.f.p,
-                       ws.pred_id.p, ws.pred_pos.p, ws.curr_max.p, ws.chain_buf.p, ws.chain_cnt.p, ws.chain_words.p);
+    {
+        const char *cv = getenv("VGA_MAP_CHAIN");  // "old": the butterfly kernel (cross-check)
+        const size_t gap_bytes = (size_t)(params->max_gap + 1) * sizeof(double);
+#define CHAIN_ARGS ws.anchor_off.p, perm, ws.s_qb.p, ws.s_tb.p, ws.s_te.p, ix.k, params->bandwidth, params->max_gap,           \
+                   params->chain_min_n_anchors, ws.gap_cost.p, ws.f.p, ws.pred_id.p, ws.pred_pos.p, ws.curr_max.p,         \
+                   ws.chain_buf.p, ws.chain_cnt.p, ws.chain_words.p
+        if (cv && strstr(cv, "old"))
+            hipLaunchKernelGGL(k_chain, dim3((unsigned)R), dim3(VGA_WAVE), 0, st, CHAIN_ARGS);
+        else if (gap_bytes <= 16 * 1024)  // (8 KB at the default max_gap; bigger tables stay in HBM)
+            hipLaunchKernelGGL(k_chain4<true>, dim3((unsigned)((R + 3) / 4)), dim3(256), gap_bytes, st, (uint32_t)R, CHAIN_ARGS);
+        else
+            hipLaunchKernelGGL(k_chain4<false>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, (uint32_t)R, CHAIN_ARGS);
+#undef CHAIN_ARGS
+    }
     vga_timer_end(ctx, t4);
     vga_timer_end(ctx, t_total);
 
