@@ -14,3 +14,4 @@ run VGA_POA_KERNEL=generic
 run VGA_POA_SLOTS=1
 run VGA_POA_SUB=7
 run VGA_POA_KERNEL=unpacked
+run VGA_MAP_CHAIN=old
