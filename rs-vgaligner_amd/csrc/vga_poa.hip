@@ -2555,6 +2555,14 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             uint32_t hg_cols = lds_cols, win_mask = 0xFFFFFFFFu;
             if (packed && !(force && strstr(force, "full"))) {
                 uint32_t want = 4096;
+                // narrow bands: a window that just covers the launch's widest estimated row (rows that turn out wider take
+                // the HBM detour) leaves room for 12 two-wave workgroups per CU instead of 7 -- such launches are bound by
+                // the latency of the per-row chain, not by instruction issue (config 5: +20 %)
+                if (mean_w <= 800.0) {
+                    uint32_t w2 = 512;
+                    while (w2 < 4096 && (double)w2 < mw * 1.25 + 16.0) w2 <<= 1;
+                    want = w2;
+                }
                 const char *ew = getenv("VGA_POA_WINDOW");
                 if (ew) want = (uint32_t)strtoul(ew, nullptr, 10);
                 if (want >= 16 && (want & (want - 1)) == 0 && want < lds_cols) { hg_cols = want; win_mask = want - 1; }
