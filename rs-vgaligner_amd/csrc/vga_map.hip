@@ -488,6 +488,19 @@ __global__ __launch_bounds__(256) void k_chain4(
     if (lane == 0) { chain_cnt[r] = nch; chain_words[r] = wpos; }
 }
 
+// the chain buffer is sized for the worst case (3 A + 2 words per read); a read uses chain_words[r] of them.  Only the
+// used prefix of every read crosses PCIe: block r copies it to its slot of the compact buffer.
+__global__ __launch_bounds__(256) void k_chain_compact(const uint64_t *__restrict__ anchor_off, const uint32_t *__restrict__ chain_words,
+                                                       const uint64_t *__restrict__ woff, const uint32_t *__restrict__ chain_buf,
+                                                       uint32_t *__restrict__ comp)
+{
+    const uint64_t r = blockIdx.x;
+    const uint32_t *src = chain_buf + 3 * anchor_off[r] + 2 * r;
+    uint32_t *dst = comp + woff[r];
+    const uint32_t n = chain_words[r];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+
 // ------------------------------------------------------------------------------------------ host
 namespace {
 
@@ -497,7 +510,9 @@ struct map_ws {
     vga_dbuf<uint32_t> a_qb, a_tb, a_te, a_idx, key_b, val_b, s_qb, s_tb, s_te;
     vga_dbuf<double> f, curr_max, gap_cost;
     vga_dbuf<int32_t> pred_id, pred_pos;
-    vga_dbuf<uint32_t> chain_buf, chain_cnt, chain_words, key_a;
+    vga_dbuf<uint32_t> chain_buf, chain_cnt, chain_words, key_a, chain_comp;
+    vga_dbuf<uint64_t> chain_woff;
+    vga_hbuf<uint64_t> h_chain_woff;
     // pinned staging for the result copies (pageable D2H runs at a fraction of the PCIe rate)
     vga_hbuf<uint32_t> h_id, h_qb, h_tb, h_te, h_chain_buf, h_chain_cnt, h_chain_words, h_cnt;
     vga_hbuf<double> h_f, h_curr_max;
@@ -693,19 +708,29 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     // ---- results to host: async copies into pinned staging, then a threaded fan-out into the result arrays
     const bool emit_dp = params->emit_dp != 0;
     if (emit_dp) { MAP_CHECK(ws.h_id.reserve(An)); MAP_CHECK(ws.h_f.reserve(An)); MAP_CHECK(ws.h_pred.reserve(An)); }
-    MAP_CHECK(ws.h_chain_buf.reserve(3 * An + 2 * R + 2));
     MAP_CHECK(ws.h_curr_max.reserve(R)); MAP_CHECK(ws.h_chain_cnt.reserve(R)); MAP_CHECK(ws.h_chain_words.reserve(R));
-    if (An) {
-        if (emit_dp) MAP_CHECK(hipMemcpyAsync(ws.h_id.p, perm, An * 4, hipMemcpyDeviceToHost, st));
-        if (emit_dp) {
-            MAP_CHECK(hipMemcpyAsync(ws.h_f.p, ws.f.p, An * 8, hipMemcpyDeviceToHost, st));
-            MAP_CHECK(hipMemcpyAsync(ws.h_pred.p, ws.pred_id.p, An * 4, hipMemcpyDeviceToHost, st));
-        }
-        MAP_CHECK(hipMemcpyAsync(ws.h_chain_buf.p, ws.chain_buf.p, (3 * An + 2 * R) * 4, hipMemcpyDeviceToHost, st));
-    }
+    MAP_CHECK(ws.h_chain_woff.reserve(R + 1)); MAP_CHECK(ws.chain_woff.reserve(R + 1));
+    // the per-read counts first: they say how much of the chain buffer is in use
     MAP_CHECK(hipMemcpyAsync(ws.h_curr_max.p, ws.curr_max.p, R * 8, hipMemcpyDeviceToHost, st));
     MAP_CHECK(hipMemcpyAsync(ws.h_chain_cnt.p, ws.chain_cnt.p, R * 4, hipMemcpyDeviceToHost, st));
     MAP_CHECK(hipMemcpyAsync(ws.h_chain_words.p, ws.chain_words.p, R * 4, hipMemcpyDeviceToHost, st));
+    if (An && emit_dp) {
+        MAP_CHECK(hipMemcpyAsync(ws.h_id.p, perm, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(ws.h_f.p, ws.f.p, An * 8, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(ws.h_pred.p, ws.pred_id.p, An * 4, hipMemcpyDeviceToHost, st));
+    }
+    MAP_CHECK(hipStreamSynchronize(st));
+    uint64_t chain_total_words = 0;
+    for (uint64_t r = 0; r < R; r++) { ws.h_chain_woff.p[r] = chain_total_words; chain_total_words += ws.h_chain_words.p[r]; }
+    ws.h_chain_woff.p[R] = chain_total_words;
+    MAP_CHECK(ws.h_chain_buf.reserve(chain_total_words + 2));
+    if (chain_total_words) {
+        MAP_CHECK(ws.chain_comp.reserve(chain_total_words + 2));
+        MAP_CHECK(hipMemcpyAsync(ws.chain_woff.p, ws.h_chain_woff.p, (R + 1) * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_chain_compact, dim3((unsigned)R), dim3(256), 0, st, ws.anchor_off.p, ws.chain_words.p, ws.chain_woff.p,
+                           ws.chain_buf.p, ws.chain_comp.p);
+        MAP_CHECK(hipMemcpyAsync(ws.h_chain_buf.p, ws.chain_comp.p, chain_total_words * 4, hipMemcpyDeviceToHost, st));
+    }
     if (emit_dp) {
         res->anchor_id = xmalloc<uint32_t>(An);
         res->max_chain_score = xmalloc<double>(An);
@@ -758,7 +783,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     res->chain_anchor_off[n_chains] = n_members;
     vga_parallel_for(R, [&](uint64_t r) {
         uint64_t ci = res->chain_off[r], mi = mem0[r];
-        const uint32_t *buf = h_chain_buf + 3 * res->anchor_off[r] + 2 * r;
+        const uint32_t *buf = h_chain_buf + ws.h_chain_woff.p[r];
         uint32_t c = h_chain_cnt[r], wp = 0;
         if (c == 0) {
             res->chain_placeholder[ci] = 1;
