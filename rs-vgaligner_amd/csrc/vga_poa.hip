@@ -593,6 +593,31 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
 }
 
 // K4b: one lane per problem.  ops are written in reverse (sink -> source) order.
+// ENC 0: direction bytes of k_poa_dp_lds / k_poa_dp_pk; ENC 1: of k_poa_dp_t4 (vga_poa_t4.hpp)
+struct tb_code { int hts, fsel, eo1, eo2, fo1, fo2; };
+template <int ENC>
+__device__ __forceinline__ tb_code tb_decode(int code)
+{
+    tb_code c;
+    if constexpr (ENC == 0) {
+        // [1:0] source of Ht (M, E1, E2), [3:2] E1/E2 opened here, [4] F1 > Ht, [5] F2 > max(Ht, F1), [7:6] F1/F2 opened here
+        c.hts = code & 3;
+        c.fsel = (code & 32) ? 2 : ((code >> 4) & 1);
+        c.eo1 = (code >> 2) & 1; c.eo2 = (code >> 3) & 1;
+        c.fo1 = (code >> 6) & 1; c.fo2 = (code >> 7) & 1;
+    } else {
+        // [7:6] tag of H (3 Ht, 1 F1, 0 F2), [5:4] tag of Ht (2 M, 1 E1, 0 E2), [3] / [2] E1 / E2 of a successor opens from
+        // this cell, [1] / [0] F1 / F2 of this cell did not open
+        const int th = (code >> 6) & 3;
+        c.hts = 2 - ((code >> 4) & 3);
+        c.fsel = th == 3 ? 0 : (th == 1 ? 1 : 2);
+        c.eo1 = (code >> 3) & 1; c.eo2 = (code >> 2) & 1;
+        c.fo1 = ((code >> 1) & 1) ^ 1; c.fo2 = (code & 1) ^ 1;
+    }
+    return c;
+}
+
+template <int ENC>
 __global__ __launch_bounds__(64) void k_poa_traceback(
     uint32_t n, const poa_prob *__restrict__ probs, const poa_row *__restrict__ rows,
     const uint32_t *__restrict__ preds, const uint8_t *__restrict__ pool, poa_out *__restrict__ outs,
@@ -609,6 +634,7 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
     uint32_t i = outs[pi].row;
     int j = (int)pb.qlen;
     int st = 0;  // 0 H, 1 E1, 2 E2, 3 F1, 4 F2, 5 Ht
+    int pend_e = 0;
     uint64_t nops = 0;
     bool bad = false;
     while (i > 0 && !bad) {
@@ -624,10 +650,13 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
         if (j < beg || j > end) { bad = true; break; }
         const uint64_t c = (uint64_t)(j - bal);
         const int code = pool[doff + c] ^ code_xor;  // the 16-bit DP kernel stores the F-open bits inverted
-        // direction byte: [1:0] source of Ht (M, E1, E2), [3:2] E1/E2 opened here, [4] F1 > Ht, [5] F2 > max(Ht, F1),
-        // [7:6] F1/F2 opened here
-        const int hts = code & 3;
-        const int fsel = (code & 32) ? 2 : ((code >> 4) & 1);  // bit 5: F2 beat everything; bit 4: F1 beat Ht (both may be set)
+        const tb_code dc = tb_decode<ENC>(code);
+        if (ENC == 1 && pend_e) {  // arrived through a deletion: this cell says whether that gap opened from it
+            if (pend_e == 1 ? dc.eo1 : dc.eo2) st = 0;
+            pend_e = 0;
+        }
+        const int hts = dc.hts;
+        const int fsel = dc.fsel;
         const int hs = fsel ? 2 + fsel : hts;
         const int src = st == 0 ? hs : (st == 5 ? hts : st);
         if (nops + 1 >= cap) { bad = true; break; }
@@ -640,12 +669,13 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
         } else if (src == 1 || src == 2) {
             const int t = np > 1 ? pool[doff + (src == 1 ? 2 : 3) * W + c] : 0;
             const uint32_t p = first ? (np == 1 ? inf.x : preds[pb.pred0 + inf.x + t]) : i - 1;
-            const int open = (code >> (src == 1 ? 2 : 3)) & 1;
+            const int open = src == 1 ? dc.eo1 : dc.eo2;
             po[nops] = 2; pr[nops] = i; nops++;
-            st = open ? 0 : src;
+            if (ENC == 1) { st = src; pend_e = src; }
+            else st = open ? 0 : src;
             i = p;
         } else {
-            const int open = (code >> (src == 3 ? 6 : 7)) & 1;
+            const int open = src == 3 ? dc.fo1 : dc.fo2;
             if (j - 1 < beg) { bad = true; break; }
             po[nops] = 1; pr[nops] = 0; nops++;
             st = open ? 5 : src;
@@ -685,6 +715,7 @@ __device__ __forceinline__ void tb_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 // every lane of the wave calls this with the same arguments (lane = its index); status / start_row are the DP's result
+template <int ENC = 0>
 __device__ __forceinline__ void poa_traceback_wave(
     tb_lds &T, const int lane, const poa_prob &pb, const poa_row *__restrict__ rows, const uint32_t *__restrict__ preds,
     const uint8_t *__restrict__ pool, poa_out &O, uint8_t *__restrict__ ops, uint32_t *__restrict__ orow, const int code_xor,
@@ -700,6 +731,7 @@ __device__ __forceinline__ void poa_traceback_wave(
     uint32_t i = start_row;
     int j = (int)pb.qlen;
     int st = 0;  // 0 H, 1 E1, 2 E2, 3 F1, 4 F2, 5 Ht
+    int pend_e = 0;
     uint32_t nops = 0;
     bool bad = false;
     uint32_t my_op = 0, my_row = 0;  // lane l keeps operation number (64 m + l) until the wave stores 64 of them together
@@ -758,10 +790,13 @@ __device__ __forceinline__ void poa_traceback_wave(
             const bool first = npred != 0;
             const int np = first ? (int)npred : 1;
             const int code = (int)((T.dir[t][off >> 2] >> (8 * (off & 3))) & 0xffu) ^ code_xor;
-            // direction byte: [1:0] source of Ht (M, E1, E2), [3:2] E1/E2 opened here, [4] F1 > Ht, [5] F2 > max(Ht, F1),
-            // [7:6] F1/F2 opened here
-            const int hts = code & 3;
-            const int fsel = (code & 32) ? 2 : ((code >> 4) & 1);
+            const tb_code dc = tb_decode<ENC>(code);
+            if (ENC == 1 && pend_e) {  // arrived through a deletion: this cell says whether that gap opened from it
+                if (pend_e == 1 ? dc.eo1 : dc.eo2) st = 0;
+                pend_e = 0;
+            }
+            const int hts = dc.hts;
+            const int fsel = dc.fsel;
             const int hs = fsel ? 2 + fsel : hts;
             const int src = st == 0 ? hs : (st == 5 ? hts : st);
             if (nops + 1 >= cap) { bad = true; break; }
@@ -786,13 +821,14 @@ __device__ __forceinline__ void poa_traceback_wave(
                     emit(0, i);
                     i = p; j -= 1; st = 0;
                 } else {
-                    const int open = (code >> (src == 1 ? 2 : 3)) & 1;
+                    const int open = src == 1 ? dc.eo1 : dc.eo2;
                     emit(2, i);
-                    st = open ? 0 : src;
+                    if (ENC == 1) { st = src; pend_e = src; }
+                    else st = open ? 0 : src;
                     i = p;
                 }
             } else {
-                const int open = (code >> (src == 3 ? 6 : 7)) & 1;
+                const int open = src == 3 ? dc.fo1 : dc.fo2;
                 if (j - 1 < beg) { bad = true; break; }
                 emit(1, 0);
                 st = open ? 5 : src;
@@ -812,6 +848,7 @@ __device__ __forceinline__ void poa_traceback_wave(
     if (lane == 0) O.nops = nops + (uint32_t)j;
 }
 
+template <int ENC>
 __global__ __launch_bounds__(64) void k_poa_traceback_wave(
     uint32_t n, const poa_prob *__restrict__ probs, const poa_row *__restrict__ rows,
     const uint32_t *__restrict__ preds, const uint8_t *__restrict__ pool, poa_out *__restrict__ outs,
@@ -821,7 +858,7 @@ __global__ __launch_bounds__(64) void k_poa_traceback_wave(
     const uint32_t pi = blockIdx.x;
     if (pi >= n) return;
     const poa_prob pb = probs[pi];
-    poa_traceback_wave(T, (int)threadIdx.x, pb, rows, preds, pool, outs[pi], ops, orow, code_xor, outs[pi].status, outs[pi].row);
+    poa_traceback_wave<ENC>(T, (int)threadIdx.x, pb, rows, preds, pool, outs[pi], ops, orow, code_xor, outs[pi].status, outs[pi].row);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2100,6 +2137,8 @@ static inline size_t poa_lds_bytes(uint32_t lds_cols, int nt)
     return 7ull * lds_cols + (size_t)(8 * nw + 3 * nw + 2) * 4 + 16;
 }
 
+#include "vga_poa_t4.hpp"
+
 // ============================================================================================ host
 namespace {
 
@@ -2320,7 +2359,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             // footprint in the pool: a direction byte per cell plus the value-row ring (packed kernel)
             if (G[p].ok) {
                 estw[p] = est_width(p);
-                est[p] = (double)G[p].N * estw[p] * 1.15 + (double)(G[p].life + 1) * 4.0 * ((double)G[p].qlen + 8.0) + 2.0 * (double)POA_CHUNK;
+                est[p] = (double)G[p].N * estw[p] * 1.15 + (double)(G[p].life + 1) * 6.0 * ((double)G[p].qlen + 8.0) + 2.0 * (double)POA_CHUNK;
             }
             ready[p] = 1;
         });
@@ -2388,6 +2427,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     while ((1 << g1b_) <= params->gap_open1 + params->gap_ext1) g1b_++;
     while ((1 << g2b_) <= params->gap_open2 + params->gap_ext2) g2b_++;
     const bool packed_k = g1b_ + g2b_ <= 8 && !(force_k && strstr(force_k, "unpacked"));
+    // k_poa_dp_t4 (vga_poa_t4.hpp), the default: scores scaled by 4 with argmax tags, G bytes 4 g - 1 / 4 g
+    const bool t4_k = packed_k && 4 * (params->gap_open1 + params->gap_ext1) - 1 <= 255 && 4 * (params->gap_open2 + params->gap_ext2) <= 255 &&
+                      params->gap_ext1 >= 1 && params->match + params->mismatch >= 0 && params->match + params->mismatch < (1 << 20) &&
+                      !(force_k && (strstr(force_k, "pk") || strstr(force_k, "full"))) && !(getenv("VGA_POA_H16") && atoi(getenv("VGA_POA_H16")) != 0) &&
+                      !getenv("VGA_POA_STAMPS");
     // traceback: fused into the packed DP kernel (default), or VGA_POA_TB=wave / lane: a kernel of its own after the DP
     const bool tb_lane = getenv("VGA_POA_TB") && strstr(getenv("VGA_POA_TB"), "lane");
     const bool tb_fused = !getenv("VGA_POA_TB") || strstr(getenv("VGA_POA_TB"), "fused");
@@ -2436,6 +2480,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     P.o2 = params->gap_open2; P.e2 = params->gap_ext2; P.banded = params->wb >= 0;
 
     bool packed_all = true;  // value rows are 4 B per cell with the packed kernel, 6 B otherwise (byte model)
+    bool t4_any = false;     // ... and 6 B with k_poa_dp_t4
     bool h16_all = true;     // ... and 3 B with 16-bit row state
     bool any_fused = false;  // the DP kernel walked the alignments back itself
     int t_total = vga_timer_begin(ctx, "poa_total", 0);
@@ -2474,6 +2519,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         }
         auto chk = [&](hipError_t e) { if (e != hipSuccess && launch_err == hipSuccess) launch_err = e; };
         bool sub_h16 = false;  // this sub-batch runs the 16-bit DP kernel
+        bool sub_t4 = false;   // ... k_poa_dp_t4 (its own direction-byte encoding)
         bool sub_fused = false;  // ... and its DP kernel does the traceback as well
         if (malformed || i1 == i0) return {i0, i0, 0.0, slot, 0};
         const int oset = (int)(S.uses++ & 1u);
@@ -2541,7 +2587,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             while ((1 << g1bits) <= P.o1 + P.e1) g1bits++;
             while ((1 << g2bits) <= P.o2 + P.e2) g2bits++;
             const bool packed = g1bits + g2bits <= 8 && !(force && strstr(force, "unpacked"));
-            packed_all = packed_all && packed;
+            const bool t4 = t4_k && packed;
+            packed_all = packed_all && packed && !t4;
+            t4_any = t4_any || t4;
             // 16-bit row state (3 B per column): default penalties only; problems it gives up on come back with use32
             const bool def_pen = P.o1 == 4 && P.e1 == 2 && P.o2 == 24 && P.e2 == 1 && !(force && strstr(force, "generic"));
             const bool h16 = packed && def_pen && !use32 && getenv("VGA_POA_H16") && atoi(getenv("VGA_POA_H16")) != 0;
@@ -2575,10 +2623,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 // workgroup size: the one that keeps the most waves resident (LDS and the 28 wave slots of a CU bound the
                 // workgroups per CU; the problems still to be run -- this sub-batch and the ones that will overlap it --
                 // bound how many there are); ties go to the smaller workgroup, whose barriers are cheaper
-                auto by_lds = [&](int t) { return std::max<size_t>(1, (160 * 1024) / (poa_pk_lds_bytes(hg_cols, lds_cols, t, h16) + 256)); };
+                auto by_lds = [&](int t) { return std::max<size_t>(1, (160 * 1024) / ((t4 ? poa_t4_lds_bytes(hg_cols, lds_cols, t) : poa_pk_lds_bytes(hg_cols, lds_cols, t, h16)) + 256)); };
                 size_t best_waves = 0;
                 for (int t = 128; t <= 512; t += 64) {
-                    const size_t per_cu = std::min<size_t>(by_lds(t), (size_t)((cpt == 8 ? 20 : 24) / (t / 64)));
+                    const size_t per_cu = std::min<size_t>(by_lds(t), (size_t)((t4 ? 16 : (cpt == 8 ? 20 : 24)) / (t / 64)));
                     const size_t waves = std::min<size_t>(order.size() - i0 + in_flight_other, per_cu * (size_t)ctx->n_cu) * (size_t)(t / 64);
                     if (waves > best_waves) { best_waves = waves; nt = t; }
                 }
@@ -2594,18 +2642,40 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 else if (strstr(force, "256")) nt = 256;
                 else if (strstr(force, "512")) nt = 512;
             }
-            auto lds_of = [&](int t) { return packed ? poa_pk_lds_bytes(hg_cols, lds_cols, t, h16) : poa_lds_bytes(lds_cols, t); };
+            auto lds_of = [&](int t) { return t4 ? poa_t4_lds_bytes(hg_cols, lds_cols, t) : (packed ? poa_pk_lds_bytes(hg_cols, lds_cols, t, h16) : poa_lds_bytes(lds_cols, t)); };
             while (nt > 128 && lds_of(nt) > 160 * 1024 - 256) nt = packed ? nt - 64 : nt / 2;
             const size_t lds = lds_of(nt);
             if (tr.on)
                 fprintf(stderr, "[vga-trace] poa: launch %u problems, NT %d, %s, window %u of %u columns, width estimate mean %.0f max %.0f, LDS %zu B\n",
-                        nb, nt, h16 ? "16-bit rows" : "32-bit rows", hg_cols, lds_cols, mean_w, mw, lds);
+                        nb, nt, t4 ? "t4 rows" : (h16 ? "16-bit rows" : "32-bit rows"), hg_cols, lds_cols, mean_w, mw, lds);
             (void)hipGetLastError();  // a launch failure below must be this launch's, not an older ignored status
 #define POA_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_sink.p, P, S.d_rows.p, pool_base,          \
                  W.d_next.p + slot, half_pool, S.d_outs.p, lds_cols
 #define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, g1bits, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr), \
                     (arena ? n_arenas : 0u), arena_size, W.d_arena_ctr.p, W.d_arena_flag.p
-            if (packed) {
+            sub_t4 = t4;
+            if (t4) {
+#define POA_T4_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, P, S.d_rows.p, pool_base, W.d_next.p + slot, half_pool,   \
+                    S.d_outs.p, lds_cols, hg_cols, win_mask, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr),       \
+                    (arena ? n_arenas : 0u), arena_size, W.d_arena_ctr.p, W.d_arena_flag.p
+#define POA_T4_LAUNCH(T)                                                                                                     \
+    case T:                                                                                                                  \
+        if (def_pen) {                                                                                                       \
+            chk(hipFuncSetAttribute((const void *)k_poa_dp_t4<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_poa_dp_t4<T, true>), dim3(nb), dim3(T), lds, st, POA_T4_ARGS);                            \
+        } else {                                                                                                             \
+            chk(hipFuncSetAttribute((const void *)k_poa_dp_t4<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_poa_dp_t4<T, false>), dim3(nb), dim3(T), lds, st, POA_T4_ARGS);                           \
+        }                                                                                                                    \
+        break;
+                switch (nt) {
+                    POA_T4_LAUNCH(128) POA_T4_LAUNCH(192) POA_T4_LAUNCH(256) POA_T4_LAUNCH(320)
+                    POA_T4_LAUNCH(384) POA_T4_LAUNCH(448) POA_T4_LAUNCH(512)
+                default: chk(hipErrorInvalidValue);
+                }
+#undef POA_T4_LAUNCH
+#undef POA_T4_ARGS
+            } else if (packed) {
                 if (getenv("VGA_POA_STAMPS") && nt == 512) {
                     // diagnostic: per-segment cycle shares of the first 64 workgroups (tid 0's wave), printed to stderr
                     static unsigned long long *d_st = nullptr;
@@ -2668,11 +2738,18 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         int t_tb = vga_timer_begin(ctx, "poa_traceback", 0, st);
         if (sub_fused) {
             // the DP kernel's first wave already walked each problem back
-        } else if (tb_lane)  // VGA_POA_TB=lane: the one-lane-per-problem walk (diagnostic / cross-check)
-            hipLaunchKernelGGL(k_poa_traceback, dim3((nb + 63) / 64), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
-                               pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, sub_h16 ? 0xC0 : 0);
+        } else if (tb_lane) {  // VGA_POA_TB=lane: the one-lane-per-problem walk (diagnostic / cross-check)
+            if (sub_t4)
+                hipLaunchKernelGGL(k_poa_traceback<1>, dim3((nb + 63) / 64), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
+                                   pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, 0);
+            else
+                hipLaunchKernelGGL(k_poa_traceback<0>, dim3((nb + 63) / 64), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
+                                   pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, sub_h16 ? 0xC0 : 0);
+        } else if (sub_t4)
+            hipLaunchKernelGGL(k_poa_traceback_wave<1>, dim3(nb), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
+                               pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, 0);
         else
-            hipLaunchKernelGGL(k_poa_traceback_wave, dim3(nb), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
+            hipLaunchKernelGGL(k_poa_traceback_wave<0>, dim3(nb), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
                                pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, sub_h16 ? 0xC0 : 0);
         vga_timer_end(ctx, t_tb);
         chk(hipMemcpyAsync(O.h_outs.p, S.d_outs.p, nb * sizeof(poa_out), hipMemcpyDeviceToHost, st));
@@ -2894,7 +2971,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     // + the value rows kept in HBM (4 B per cell packed, 6 B otherwise), written once and read back at least once
     for (auto &a : ctx->last_times) {
         // (the traceback's 6 bytes per alignment column belong to whichever kernel walked: the DP kernel when fused)
-        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + (h16_all ? 6 : (packed_all ? 8 : 12)) * all_vcells + (any_fused ? 6 * all_ops : 0);
+        if (a.name == "poa_band_dp") a.bytes = all_rows + all_q + all_cells + (t4_any ? 12 : (h16_all ? 6 : (packed_all ? 8 : 12))) * all_vcells + (any_fused ? 6 * all_ops : 0);
         if (a.name == "poa_traceback") a.bytes = any_fused ? 0 : 6 * all_ops;
     }
     tm.ms_dp = vga_timer_sum(ctx, "poa_band_dp");

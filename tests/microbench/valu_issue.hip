@@ -18,10 +18,10 @@
 #define R32(OP, TAIL) R8(OP, TAIL) R8(OP, TAIL) R8(OP, TAIL) R8(OP, TAIL)
 #define BODY2(OP, TAIL) asm volatile(R32(OP, TAIL) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b))
 
-enum { K_ADD, K_MAX, K_MAXDPP, K_PKADD, K_PKMAX, K_MAX3, K_LSHLOR, K_PERM, K_SDWA, K_CNDMASK, K_CMPCND, K_READLANE, K_DEP, K_MIXSALU, K_MOVDPP, K_BFE, K_SUB, K_AND, K_OR, K_XOR, K_LSHL, K_ASHR, K_MIN, K_MINU, K_ADD3, K_OR3, K_ANDOR, K_LSHLADD, K_MAD24, K_MADU24, K_MED3, K_PKSUB, K_PKMIN, K_PKMAD, K_PKLSHR, K_ADDF, K_FMA, K_MULLO, K_ALIGNBIT, K_SAD, K_ADDCO, K_SUBREV, K_MOV, K_MAXU16, K_ADD_SGPR, K_MAX_SGPR, K_CND_VCC_SALU, K_CND_SPAIR_SALU, K_CND_SPAIR_VALU, K_CND_ROT4, K_ADD_LIT, K_MAX_INL, K_SUBB_CHAIN, K_NKINDS };
+enum { K_ADD, K_MAX, K_MAXDPP, K_PKADD, K_PKMAX, K_MAX3, K_LSHLOR, K_PERM, K_SDWA, K_CNDMASK, K_CMPCND, K_READLANE, K_DEP, K_MIXSALU, K_MOVDPP, K_BFE, K_SUB, K_AND, K_OR, K_XOR, K_LSHL, K_ASHR, K_MIN, K_MINU, K_ADD3, K_OR3, K_ANDOR, K_LSHLADD, K_MAD24, K_MADU24, K_MED3, K_PKSUB, K_PKMIN, K_PKMAD, K_PKLSHR, K_ADDF, K_FMA, K_MULLO, K_ALIGNBIT, K_SAD, K_ADDCO, K_SUBREV, K_MOV, K_MAXU16, K_ADD_SGPR, K_MAX_SGPR, K_CND_VCC_SALU, K_CND_SPAIR_SALU, K_CND_SPAIR_VALU, K_CND_ROT4, K_ADD_LIT, K_MAX_INL, K_SUBB_CHAIN, K_SSXX, K_S4X4, K_S3X1, K_ADD_INL, K_SX_DIFFWAVE, K_MAX3_SALU11, K_MAX3_SALU21, K_MAX3_SALU12, K_MAX3_BR, K_NKINDS };
 static const char *kind_name[] = {"v_add_u32", "v_max_i32", "v_max_i32_dpp row_shr:1", "v_pk_add_i16", "v_pk_max_i16", "v_max3_i32", "v_lshl_or_b32",
                                   "v_perm_b32", "v_sub_u32_sdwa BYTE_0", "v_cndmask_b32 (vcc)", "v_cmp_gt_i32 + v_cndmask_b32 pairs", "v_readlane_b32",
-                                  "v_add_u32 dependent chain", "v_add_u32 + s_add_u32 1:1", "v_mov_b32_dpp row_shr:1", "v_bfe_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_min_i32", "v_min_u32", "v_add3_u32", "v_or3_b32", "v_and_or_b32", "v_lshl_add_u32", "v_mad_i32_i24", "v_mad_u32_u24", "v_med3_i32", "v_pk_sub_i16", "v_pk_min_i16", "v_pk_mad_u16", "v_pk_lshrrev_b16", "v_add_f32", "v_fma_f32", "v_mul_lo_u32", "v_alignbit_b32", "v_sad_u32", "v_add_co_u32", "v_subrev_u32", "v_mov_b32", "v_max_u16", "v_add_u32 v, s, v (SGPR operand)", "v_max_i32 v, s, v (SGPR operand)", "v_cndmask_b32 vcc (vcc written by SALU)", "v_cndmask_b32_e64 mask in s[a:b] written by SALU", "v_cndmask_b32_e64 mask in s[a:b] written by v_cmp", "v_cndmask_b32_e64 rotating over 4 SGPR-pair masks (v_cmp written)", "v_add_u32 v, 0x12345, v (literal)", "v_max_i32 v, 5, v (inline const)", "v_sub_u32 then v_min_i32 alternating"};
+                                  "v_add_u32 dependent chain", "v_add_u32 + s_add_u32 1:1", "v_mov_b32_dpp row_shr:1", "v_bfe_u32", "v_sub_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_min_i32", "v_min_u32", "v_add3_u32", "v_or3_b32", "v_and_or_b32", "v_lshl_add_u32", "v_mad_i32_i24", "v_mad_u32_u24", "v_med3_i32", "v_pk_sub_i16", "v_pk_min_i16", "v_pk_mad_u16", "v_pk_lshrrev_b16", "v_add_f32", "v_fma_f32", "v_mul_lo_u32", "v_alignbit_b32", "v_sad_u32", "v_add_co_u32", "v_subrev_u32", "v_mov_b32", "v_max_u16", "v_add_u32 v, s, v (SGPR operand)", "v_max_i32 v, s, v (SGPR operand)", "v_cndmask_b32 vcc (vcc written by SALU)", "v_cndmask_b32_e64 mask in s[a:b] written by SALU", "v_cndmask_b32_e64 mask in s[a:b] written by v_cmp", "v_cndmask_b32_e64 rotating over 4 SGPR-pair masks (v_cmp written)", "v_add_u32 v, 0x12345, v (literal)", "v_max_i32 v, 5, v (inline const)", "v_sub_u32 then v_min_i32 alternating", "v_sub,v_sub,v_min,v_min repeating", "v_sub x4 then v_min x4 repeating", "v_sub x3 then v_min x1 repeating", "v_add_u32 v, 4, v (inline const)", "(unused)", "v_max3_i32 + s_add_u32 1:1 (VALU rate)", "v_max3_i32 x2 + s_add_u32 x1 (VALU rate)", "v_max3_i32 x1 + s_add_u32 x2 (VALU rate)", "v_max3_i32 x4 + s_cmp/s_cbranch (not taken) (VALU rate)"};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_issue(int iters, unsigned long long *cyc, int *sink)
@@ -126,6 +126,38 @@ __global__ __launch_bounds__(256) void k_issue(int iters, unsigned long long *cy
 #define SM(n) "v_sub_u32 %" #n ", %" #n ", %8\n\tv_min_i32 %" #n ", %" #n ", %8\n\t"
             asm volatile(SM(0) SM(1) SM(2) SM(3) SM(4) SM(5) SM(6) SM(7) SM(0) SM(1) SM(2) SM(3) SM(4) SM(5) SM(6) SM(7)
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        }
+        else if constexpr (KIND == K_SSXX) {
+#define S_(n) "v_sub_u32 %" #n ", %" #n ", %8\n\t"
+#define X_(n) "v_min_i32 %" #n ", %" #n ", %8\n\t"
+            asm volatile(S_(0) S_(1) X_(2) X_(3) S_(4) S_(5) X_(6) X_(7) S_(0) S_(1) X_(2) X_(3) S_(4) S_(5) X_(6) X_(7) S_(0) S_(1) X_(2) X_(3) S_(4) S_(5) X_(6) X_(7) S_(0) S_(1) X_(2) X_(3) S_(4) S_(5) X_(6) X_(7)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        } else if constexpr (KIND == K_S4X4) {
+            asm volatile(S_(0) S_(1) S_(2) S_(3) X_(4) X_(5) X_(6) X_(7) S_(0) S_(1) S_(2) S_(3) X_(4) X_(5) X_(6) X_(7) S_(0) S_(1) S_(2) S_(3) X_(4) X_(5) X_(6) X_(7) S_(0) S_(1) S_(2) S_(3) X_(4) X_(5) X_(6) X_(7)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        } else if constexpr (KIND == K_S3X1) {
+            asm volatile(S_(0) S_(1) S_(2) X_(3) S_(4) S_(5) S_(6) X_(7) S_(0) S_(1) S_(2) X_(3) S_(4) S_(5) S_(6) X_(7) S_(0) S_(1) S_(2) X_(3) S_(4) S_(5) S_(6) X_(7) S_(0) S_(1) S_(2) X_(3) S_(4) S_(5) S_(6) X_(7)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));
+        } else if constexpr (KIND == K_ADD_INL) {
+#define AI(n) "v_add_u32 %" #n ", 4, %" #n "\n\t"
+            asm volatile(AI(0) AI(1) AI(2) AI(3) AI(4) AI(5) AI(6) AI(7) AI(0) AI(1) AI(2) AI(3) AI(4) AI(5) AI(6) AI(7) AI(0) AI(1) AI(2) AI(3) AI(4) AI(5) AI(6) AI(7) AI(0) AI(1) AI(2) AI(3) AI(4) AI(5) AI(6) AI(7)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        }
+        else if constexpr (KIND == K_MAX3_SALU11) {
+#define M3(n) "v_max3_i32 %" #n ", %" #n ", %12, %12\n\t"
+#define SA(s) "s_add_u32 %" #s ", %" #s ", 3\n\t"
+            asm volatile(M3(0) SA(8) M3(1) SA(9) M3(2) SA(10) M3(3) SA(11) M3(4) SA(8) M3(5) SA(9) M3(6) SA(10) M3(7) SA(11) M3(0) SA(8) M3(1) SA(9) M3(2) SA(10) M3(3) SA(11) M3(4) SA(8) M3(5) SA(9) M3(6) SA(10) M3(7) SA(11)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(b) : "scc");
+        } else if constexpr (KIND == K_MAX3_SALU21) {
+            asm volatile(M3(0) M3(1) SA(8) M3(2) M3(3) SA(9) M3(4) M3(5) SA(10) M3(6) M3(7) SA(11) M3(0) M3(1) SA(8) M3(2) M3(3) SA(9) M3(4) M3(5) SA(10) M3(6) M3(7) SA(11)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(b) : "scc");
+        } else if constexpr (KIND == K_MAX3_SALU12) {
+            asm volatile(M3(0) SA(8) SA(9) M3(1) SA(10) SA(11) M3(2) SA(8) SA(9) M3(3) SA(10) SA(11) M3(4) SA(8) SA(9) M3(5) SA(10) SA(11) M3(6) SA(8) SA(9) M3(7) SA(10) SA(11) M3(0) SA(8) SA(9) M3(1) SA(10) SA(11) M3(2) SA(8) SA(9) M3(3) SA(10) SA(11) M3(4) SA(8) SA(9) M3(5) SA(10) SA(11) M3(6) SA(8) SA(9) M3(7) SA(10) SA(11)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(b) : "scc");
+        } else if constexpr (KIND == K_MAX3_BR) {
+#define BR(s, l) "s_cmp_eq_u32 %" #s ", 0x7fffffff\n\ts_cbranch_scc1 1f\n\t"
+            asm volatile(M3(0) M3(1) M3(2) M3(3) BR(8, 1) M3(4) M3(5) M3(6) M3(7) BR(9, 2) M3(0) M3(1) M3(2) M3(3) BR(10, 3) M3(4) M3(5) M3(6) M3(7) BR(11, 4) "1:\n\t"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(b) : "scc");
         } else if constexpr (KIND == K_ADDCO) {
 #define AC(n) "v_add_co_u32 %" #n ", vcc, %" #n ", %8\n\t"
             asm volatile(AC(0) AC(1) AC(2) AC(3) AC(4) AC(5) AC(6) AC(7) AC(0) AC(1) AC(2) AC(3) AC(4) AC(5) AC(6) AC(7) AC(0) AC(1) AC(2) AC(3) AC(4) AC(5) AC(6) AC(7) AC(0) AC(1) AC(2) AC(3) AC(4) AC(5) AC(6) AC(7)
@@ -142,7 +174,7 @@ __global__ __launch_bounds__(256) void k_issue(int iters, unsigned long long *cy
     if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + s0 + s1 + s2 + s3 == 0x7fffffff) sink[0] = 1;
 }
 
-static int insts_per_trip(int kind) { return kind == K_MIXSALU ? 16 : 32; }  // VALU instructions per loop trip (K_CMPCND: 32 = 16 cmp + 16 cndmask)
+static int insts_per_trip(int kind) { return kind == K_MIXSALU || kind == K_MAX3_SALU11 || kind == K_MAX3_SALU21 || kind == K_MAX3_SALU12 || kind == K_MAX3_BR ? 16 : 32; }  // VALU instructions per loop trip (K_CMPCND: 32 = 16 cmp + 16 cndmask)
 
 template <int KIND>
 static void run(int cus, unsigned long long *d_cyc, int *d_sink)
@@ -175,8 +207,9 @@ static void run(int cus, unsigned long long *d_cyc, int *d_sink)
     CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool only_new = argc > 1;
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
@@ -184,6 +217,11 @@ int main()
     unsigned long long *d_cyc; int *d_sink;
     CK(hipMalloc(&d_cyc, (size_t)cus * 8 * 4 * 8));
     CK(hipMalloc(&d_sink, 4));
+    if (only_new) {
+        run<K_SUB>(cus, d_cyc, d_sink); run<K_MIN>(cus, d_cyc, d_sink); run<K_SUBB_CHAIN>(cus, d_cyc, d_sink); run<K_SSXX>(cus, d_cyc, d_sink); run<K_S4X4>(cus, d_cyc, d_sink); run<K_S3X1>(cus, d_cyc, d_sink); run<K_ADD_INL>(cus, d_cyc, d_sink);
+        run<K_MAX3>(cus, d_cyc, d_sink); run<K_MAX3_SALU11>(cus, d_cyc, d_sink); run<K_MAX3_SALU21>(cus, d_cyc, d_sink); run<K_MAX3_SALU12>(cus, d_cyc, d_sink); run<K_MAX3_BR>(cus, d_cyc, d_sink);
+        return 0;
+    }
     run<K_ADD>(cus, d_cyc, d_sink);
     run<K_MAX>(cus, d_cyc, d_sink);
     run<K_MAXDPP>(cus, d_cyc, d_sink);
