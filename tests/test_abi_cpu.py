@@ -24,13 +24,62 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert L.vga_abi_version() == 3
 
 
-def test_struct_layouts_match_header():
-    p = pkg()
-    b = p.binding
-    assert C.sizeof(b.KmerPos) == 24
-    assert C.sizeof(b.MapParams) == 32
-    assert C.sizeof(b.PoaParams) == 40
-    assert b.KMERPOS_DTYPE.itemsize == 24
+# every struct of include/vga_hip.h and the ctypes class binding.py declares for it
+ABI_STRUCTS = {
+    "vga_kmerpos": "KmerPos", "vga_index_desc": "IndexDesc", "vga_map_params": "MapParams", "vga_map_result": "MapResult",
+    "vga_poa_params": "PoaParams", "vga_poa_result": "PoaResult", "vga_align_result": "AlignResult", "vga_kernel_time": "KernelTime",
+}
+
+
+def _header_structs():
+    """{struct name: [field names in declaration order]} parsed from include/vga_hip.h."""
+    header = open(os.path.join(ROOT, "include", "vga_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    out = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(vga_[a-z_]+)\s*;", header, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                fields.append(re.findall(r"([A-Za-z_][A-Za-z_0-9]*)\s*$", part.strip())[0])
+        out[name] = fields
+    return out
+
+
+def test_header_is_plain_c99_and_layouts_match_ctypes(tmp_path):
+    """Compiles a C99 program against include/vga_hip.h (gcc -std=c99 -Wall -Werror -pedantic), lets it print sizeof of every
+    struct and offsetof of every field, and compares with the ctypes classes of binding.py field by field: a silent
+    reorder or a changed type on either side fails here."""
+    import subprocess
+
+    structs = _header_structs()
+    assert set(structs) == set(ABI_STRUCTS), set(structs) ^ set(ABI_STRUCTS)
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "vga_hip.h"', "int main(void) {"]
+    for name, fields in structs.items():
+        src.append('  printf("S %s %%zu\\n", sizeof(%s));' % (name, name))
+        for f in fields:
+            src.append('  printf("F %s %s %%zu %%zu\\n", offsetof(%s, %s), sizeof(((%s *)0)->%s));' % (name, f, name, f, name, f))
+    src += ['  printf("V %d\\n", VGA_OK + VGA_ERR_ARG + VGA_ERR_HIP + VGA_ERR_NOMEM + VGA_ERR_UNSUPPORTED + VGA_ERR_NO_INDEX + VGA_ERR_NO_DEVICE + VGA_ERR_POOL);',
+            "  return 0;", "}"]
+    cfile = tmp_path / "abi.c"
+    cfile.write_text("\n".join(src) + "\n")
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(cfile), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True).split("\n")
+    sizes = {l.split()[1]: int(l.split()[2]) for l in out if l.startswith("S ")}
+    offs = {(l.split()[1], l.split()[2]): (int(l.split()[3]), int(l.split()[4])) for l in out if l.startswith("F ")}
+    b = pkg().binding
+    for name, cls_name in ABI_STRUCTS.items():
+        cls = getattr(b, cls_name)
+        assert C.sizeof(cls) == sizes[name], (name, C.sizeof(cls), sizes[name])
+        assert [f[0] for f in cls._fields_] == structs[name], (name, [f[0] for f in cls._fields_], structs[name])
+        for fname, ftype in cls._fields_:
+            d = getattr(cls, fname)
+            assert (d.offset, d.size) == offs[(name, fname)], (name, fname, (d.offset, d.size), offs[(name, fname)])
+    assert b.KMERPOS_DTYPE.itemsize == sizes["vga_kmerpos"] == 24
+    assert sizes["vga_map_params"] == 32 and sizes["vga_poa_params"] == 40
 
 
 def test_no_cpu_fallback_without_gpu():
