@@ -72,6 +72,7 @@ def main():
     if world > 1 and "VGA_HOST_THREADS" not in os.environ:
         os.environ["VGA_HOST_THREADS"] = str(max(4, min(32, (os.cpu_count() or 32) // world)))
 
+    os.environ.setdefault("VGA_TUNE_MALLOC", "1")  # opt in: result arrays stay in the heap between calls (vga_ctx_create)
     import __graft_entry__ as ge
 
     pkg = ge.load_package()

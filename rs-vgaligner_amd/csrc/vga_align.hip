@@ -250,7 +250,7 @@ extern "C" void vga_align_result_free(vga_align_result *r)
     free(r);
 }
 
-extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t align_best_n, const vga_poa_params *params,
+static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t align_best_n, const vga_poa_params *params,
                                vga_align_result **out)
 {
     if (!b || !m || !params || !out || !b->ctx) return VGA_ERR_ARG;  // b->ctx == nullptr: the context was destroyed
@@ -340,6 +340,8 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
 
     // ---- per read: keep the candidate with the longest path (stable, align.rs:52-54)
     vga_align_result *res = (vga_align_result *)calloc(1, sizeof(vga_align_result));
+    if (!res) return vga_set_error(ctx, VGA_ERR_NOMEM, "out of host memory (align result)");
+    auto nomem = [&]() { vga_align_result_free(res); return vga_set_error(ctx, VGA_ERR_NOMEM, "out of host memory (align result of %llu reads)", (unsigned long long)R); };
     res->n_reads = R;
     res->aligned = amalloc<uint8_t>(R);
     res->path_off = amalloc<uint64_t>(R + 1);
@@ -350,6 +352,9 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
     res->best_score = amalloc<int32_t>(R);
     res->cigar_off = amalloc<uint64_t>(R + 1);
     res->cs_off = amalloc<uint64_t>(R + 1);
+    if (!res->aligned || !res->path_off || !res->path_length || !res->path_start || !res->path_end || !res->block_length || !res->best_score ||
+        !res->cigar_off || !res->cs_off)
+        return nomem();
     std::vector<int64_t> pick(R, -1);
     std::vector<uint32_t> path_n(R, 0);
     vga_parallel_for(R, [&](uint64_t r) {
@@ -378,6 +383,7 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
     res->path_handles = amalloc<uint64_t>(tp);
     res->cigar = amalloc<char>(tc);
     res->cs = amalloc<char>(ts);
+    if (!res->path_handles || !res->cigar || !res->cs) return nomem();
     vga_parallel_for(R, [&](uint64_t r) {
         res->aligned[r] = pick[r] >= 0;
         res->path_length[r] = res->path_start[r] = res->path_end[r] = res->block_length[r] = 0;
@@ -416,3 +422,17 @@ extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t a
     *out = res;
     return VGA_OK;
 }
+
+extern "C" int vga_align_batch(vga_batch *b, const vga_map_result *m, uint32_t align_best_n, const vga_poa_params *params,
+                               vga_align_result **out)
+{
+    // nothing throws across the C ABI: an allocation failure inside becomes VGA_ERR_NOMEM
+    try {
+        return vga_align_batch_impl(b, m, align_best_n, params, out);
+    } catch (const std::bad_alloc &) {
+        return vga_set_error((b ? b->ctx : nullptr), VGA_ERR_NOMEM, "vga_align_batch: out of host memory");
+    } catch (const std::exception &e) {
+        return vga_set_error((b ? b->ctx : nullptr), VGA_ERR_ARG, "vga_align_batch: %s", e.what());
+    }
+}
+

@@ -7,6 +7,8 @@
 // exact map gives the same answers, and 4^11 * 4 B = 16 MiB sits in the 256 MiB Infinity Cache.
 #include "vga_common.hpp"
 
+#include <mutex>
+
 #include <algorithm>
 
 #include <malloc.h>
@@ -45,16 +47,18 @@ extern "C" int vga_ctx_create(int device, vga_ctx **out)
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0 || device < 0 || device >= n) return VGA_ERR_NO_DEVICE;
     {
-        // Every call moves gigabytes of results through malloc'd arrays.  With glibc's defaults those come from
-        // mmap and go back to the kernel on free, so each call pays the page faults again (hundreds of ms per
-        // 10k-read batch).  Keep the memory in the heap instead.  VGA_KEEP_MALLOC_DEFAULTS=1 opts out.
-        static bool tuned = false;
-        if (!tuned && !getenv("VGA_KEEP_MALLOC_DEFAULTS")) {
-            mallopt(M_MMAP_THRESHOLD, 1 << 30);
-            mallopt(M_TRIM_THRESHOLD, INT32_MAX);
-            mallopt(M_TOP_PAD, 256 << 20);
-            tuned = true;
-        }
+        // Every call moves gigabytes of results through malloc'd arrays.  With glibc's defaults those come from mmap and go
+        // back to the kernel on free, so each call pays the page faults again (hundreds of ms per 10k-read batch).  A host
+        // process that wants them kept in the heap opts in with VGA_TUNE_MALLOC=1 (the `vgaligner` CLI and bench.py do):
+        // the library does not change the allocator behaviour of a process that embeds it unasked.
+        static std::once_flag tuned;
+        const char *tm = getenv("VGA_TUNE_MALLOC");
+        if (tm && atoi(tm) != 0)
+            std::call_once(tuned, []() {
+                mallopt(M_MMAP_THRESHOLD, 1 << 30);
+                mallopt(M_TRIM_THRESHOLD, INT32_MAX);
+                mallopt(M_TOP_PAD, 256 << 20);
+            });
     }
     vga_ctx *ctx = new vga_ctx();
     ctx->device = device;
@@ -210,7 +214,7 @@ static inline int vga_base_code(char c)
     }
 }
 
-extern "C" int vga_index_upload(vga_ctx *ctx, const vga_index_desc *d)
+static int vga_index_upload_impl(vga_ctx *ctx, const vga_index_desc *d)
 {
     if (!ctx || !d) return VGA_ERR_ARG;
     (void)hipSetDevice(ctx->device);
@@ -297,8 +301,21 @@ extern "C" int vga_index_upload(vga_ctx *ctx, const vga_index_desc *d)
     return VGA_OK;
 }
 
+extern "C" int vga_index_upload(vga_ctx *ctx, const vga_index_desc *d)
+{
+    // nothing throws across the C ABI: an allocation failure inside becomes VGA_ERR_NOMEM
+    try {
+        return vga_index_upload_impl(ctx, d);
+    } catch (const std::bad_alloc &) {
+        return vga_set_error(ctx, VGA_ERR_NOMEM, "vga_index_upload: out of host memory");
+    } catch (const std::exception &e) {
+        return vga_set_error(ctx, VGA_ERR_ARG, "vga_index_upload: %s", e.what());
+    }
+}
+
+
 // ---------------------------------------------------------------- read batches
-extern "C" int vga_batch_create(vga_ctx *ctx, const char *reads_concat, const uint64_t *read_off, uint64_t n_reads,
+static int vga_batch_create_impl(vga_ctx *ctx, const char *reads_concat, const uint64_t *read_off, uint64_t n_reads,
                                 vga_batch **out)
 {
     if (!ctx || !out || !read_off || (!reads_concat && n_reads && read_off[n_reads])) return VGA_ERR_ARG;
@@ -330,6 +347,20 @@ extern "C" int vga_batch_create(vga_ctx *ctx, const char *reads_concat, const ui
     *out = b;
     return VGA_OK;
 }
+
+extern "C" int vga_batch_create(vga_ctx *ctx, const char *reads_concat, const uint64_t *read_off, uint64_t n_reads,
+                                vga_batch **out)
+{
+    // nothing throws across the C ABI: an allocation failure inside becomes VGA_ERR_NOMEM
+    try {
+        return vga_batch_create_impl(ctx, reads_concat, read_off, n_reads, out);
+    } catch (const std::bad_alloc &) {
+        return vga_set_error(ctx, VGA_ERR_NOMEM, "vga_batch_create: out of host memory");
+    } catch (const std::exception &e) {
+        return vga_set_error(ctx, VGA_ERR_ARG, "vga_batch_create: %s", e.what());
+    }
+}
+
 
 extern "C" void vga_batch_destroy(vga_batch *b)
 {

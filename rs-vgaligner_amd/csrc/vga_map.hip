@@ -553,7 +553,7 @@ extern "C" void vga_map_result_free(vga_map_result *r)
     free(r);
 }
 
-extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map_result **out)
+static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_map_result **out)
 {
     if (!b || !params || !out || !b->ctx) return VGA_ERR_ARG;  // b->ctx == nullptr: the context was destroyed
     vga_ctx *ctx = b->ctx;
@@ -579,14 +579,19 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     vga_trace tr("map");
 
     vga_map_result *res = (vga_map_result *)calloc(1, sizeof(vga_map_result));
+    if (!res) return vga_set_error(ctx, VGA_ERR_NOMEM, "out of host memory (map result)");
+    // every host allocation of the result is checked before it is written to: VGA_ERR_NOMEM instead of a crash
+    auto nomem = [&]() { vga_map_result_free(res); return vga_set_error(ctx, VGA_ERR_NOMEM, "out of host memory (map result of %llu reads)", (unsigned long long)R); };
     res->n_reads = R;
     res->anchor_off = xmalloc<uint64_t>(R + 1);
     res->curr_max = xmalloc<double>(R);
     res->chain_off = xmalloc<uint64_t>(R + 1);
+    if (!res->anchor_off || !res->curr_max || !res->chain_off) return nomem();
     res->anchor_off[0] = 0;
     res->chain_off[0] = 0;
     if (R == 0) {
         res->chain_anchor_off = xmalloc<uint64_t>(1);
+        if (!res->chain_anchor_off) return nomem();
         res->chain_anchor_off[0] = 0;
         *out = res;
         return VGA_OK;
@@ -739,6 +744,11 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     res->query_begin = xmalloc<uint32_t>(An);
     res->target_begin = xmalloc<uint32_t>(An);
     res->target_end = xmalloc<uint32_t>(An);
+    if ((emit_dp && (!res->anchor_id || !res->max_chain_score || !res->best_pred_id)) || !res->query_begin || !res->target_begin || !res->target_end) {
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(ws.st_copy);
+        return nomem();
+    }
     MAP_CHECK(hipStreamSynchronize(st));
     MAP_CHECK(hipStreamSynchronize(ws.st_copy));
     tr.mark("kernels + D2H");
@@ -780,6 +790,7 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     res->chain_placeholder = xmalloc<uint8_t>(n_chains);
     res->chain_anchor_off = xmalloc<uint64_t>(n_chains + 1);
     res->chain_anchor_idx = xmalloc<uint32_t>(n_members);
+    if (!res->chain_placeholder || !res->chain_anchor_off || !res->chain_anchor_idx) return nomem();
     res->chain_anchor_off[n_chains] = n_members;
     vga_parallel_for(R, [&](uint64_t r) {
         uint64_t ci = res->chain_off[r], mi = mem0[r];
@@ -809,3 +820,16 @@ extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map
     *out = res;
     return VGA_OK;
 }
+
+extern "C" int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map_result **out)
+{
+    // nothing throws across the C ABI: an allocation failure inside becomes VGA_ERR_NOMEM
+    try {
+        return vga_map_batch_impl(b, params, out);
+    } catch (const std::bad_alloc &) {
+        return vga_set_error((b ? b->ctx : nullptr), VGA_ERR_NOMEM, "vga_map_batch: out of host memory");
+    } catch (const std::exception &e) {
+        return vga_set_error((b ? b->ctx : nullptr), VGA_ERR_ARG, "vga_map_batch: %s", e.what());
+    }
+}
+

@@ -2865,7 +2865,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         if (!todo.empty()) ensure(todo.back().first, std::min<uint64_t>(todo.back().second, todo.back().first + 1536));
         const sub_t cur = inflight.front();
         inflight.erase(inflight.begin());
-        POA_CHECK(hipStreamSynchronize(sarr[cur.slot]));
+        {
+            const hipError_t se = hipStreamSynchronize(sarr[cur.slot]);
+            if (se != hipSuccess) { launch_err = se; break; }  // (falls through to the drain of every stream below)
+        }
         const poa_slot::out_set &S = W.slot[cur.slot].outs[cur.oset];
         if (launch_err != hipSuccess) break;
         bool pool_fail = false;
@@ -2990,7 +2993,7 @@ extern "C" void vga_poa_result_free(vga_poa_result *r)
     free(r);
 }
 
-extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr, const uint64_t *node_off,
+static int vga_poa_batch_impl(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr, const uint64_t *node_off,
                              const char *nodes_concat, const uint64_t *edge_ptr, const uint32_t *edge_src,
                              const uint32_t *edge_dst, const uint64_t *query_off, const char *queries_concat,
                              const vga_poa_params *params, vga_poa_result **out)
@@ -3012,6 +3015,8 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     int rc = poa_run(ctx, feed, params, items, tm);
     if (rc != VGA_OK) return rc;
     vga_poa_result *res = (vga_poa_result *)calloc(1, sizeof(vga_poa_result));
+    if (!res) return vga_set_error(ctx, VGA_ERR_NOMEM, "out of host memory (POA result)");
+    auto nomem = [&]() { vga_poa_result_free(res); return vga_set_error(ctx, VGA_ERR_NOMEM, "out of host memory (POA result of %llu problems)", (unsigned long long)n); };
     res->n = n;
     res->ok = pmalloc<uint8_t>(n);
     res->best_score = pmalloc<int32_t>(n);
@@ -3024,6 +3029,9 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     res->n_rows = pmalloc<uint64_t>(n);
     res->n_cells = pmalloc<uint64_t>(n);
     res->n_value_cells = pmalloc<uint64_t>(n);
+    if (!res->ok || !res->best_score || !res->path_off || !res->aln_start_offset || !res->aln_end_offset || !res->n_aligned_bases ||
+        !res->cigar_off || !res->cs_off || !res->n_rows || !res->n_cells || !res->n_value_cells)
+        return nomem();
     uint64_t tp = 0, tc = 0, ts = 0;
     for (uint64_t p = 0; p < n; p++) {
         res->path_off[p] = tp; res->cigar_off[p] = tc; res->cs_off[p] = ts;
@@ -3034,6 +3042,7 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     res->graph_nodes = pmalloc<uint32_t>(tp);
     res->cigar = pmalloc<char>(tc);
     res->cs = pmalloc<char>(ts);
+    if (!res->abpoa_nodes || !res->graph_nodes || !res->cigar || !res->cs) return nomem();
     for (uint64_t p = 0; p < n; p++) {
         const poa_item &it = items[p];
         res->ok[p] = it.ok; res->best_score[p] = it.score; res->aln_start_offset[p] = it.start_off;
@@ -3052,3 +3061,19 @@ extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr,
     *out = res;
     return VGA_OK;
 }
+
+extern "C" int vga_poa_batch(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr, const uint64_t *node_off,
+                             const char *nodes_concat, const uint64_t *edge_ptr, const uint32_t *edge_src,
+                             const uint32_t *edge_dst, const uint64_t *query_off, const char *queries_concat,
+                             const vga_poa_params *params, vga_poa_result **out)
+{
+    // nothing throws across the C ABI: an allocation failure inside becomes VGA_ERR_NOMEM
+    try {
+        return vga_poa_batch_impl(ctx, n, node_ptr, node_off, nodes_concat, edge_ptr, edge_src, edge_dst, query_off, queries_concat, params, out);
+    } catch (const std::bad_alloc &) {
+        return vga_set_error(ctx, VGA_ERR_NOMEM, "vga_poa_batch: out of host memory");
+    } catch (const std::exception &e) {
+        return vga_set_error(ctx, VGA_ERR_ARG, "vga_poa_batch: %s", e.what());
+    }
+}
+

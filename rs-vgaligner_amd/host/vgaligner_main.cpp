@@ -3,6 +3,7 @@
 #include "vgh.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 
@@ -27,7 +28,9 @@ const Flag MAP_FLAGS[] = {{"-i", "--index", true, "index"}, {"-f", "--input-file
                           {"-v", "--also-validate", false, "also-validate"}, {"-G", "--graph", true, "graph"},
                           {"-P", "--validation-path", true, "validation-path"}, {"-p", "--poa-aligner", true, "poa-aligner"},
                           {"", "--out-prefix", true, "out-prefix"}, {"", "--n-threads", true, "n-threads"},
-                          {"-d", "--device", true, "device"}};  // --device: which GPU (not in the reference)
+                          // not in the reference: --device one GPU, --devices a list (one context + host thread each; an id may
+                          // repeat; default: every visible GPU), --chunk-reads reads per batch (bounded memory; 0 = one batch)
+                          {"-d", "--device", true, "device"}, {"", "--devices", true, "devices"}, {"", "--chunk-reads", true, "chunk-reads"}};
 
 template <size_t N>
 std::map<std::string, std::string> parse(const Flag (&flags)[N], int argc, char **argv, int first)
@@ -102,17 +105,24 @@ int map_main(int argc, char **argv)
     Index ix = Index::load(exact ? idx : idx + ".idx");
     std::vector<QuerySequence> reads = read_seqs_from_file(in);
     fprintf(stderr, "[vgaligner] Found %zu reads!\n", reads.size());
-    vga_ctx *ctx = nullptr;
-    if (vga_ctx_create(o.device, &ctx) != VGA_OK) throw Error("no MI355X device available (this build has no CPU path)");
-    vga_index_desc d;
-    Index::DescScratch sc;
-    ix.describe(d, sc);
-    if (vga_index_upload(ctx, &d) != VGA_OK) { std::string e = vga_last_error(ctx); vga_ctx_destroy(ctx); throw Error(e); }
-    MapOutput out = map_reads(ctx, ix, reads, o, prefix);
+    if (m.count("devices")) {
+        const std::string l = m["devices"];
+        size_t p0 = 0;
+        while (p0 <= l.size()) {
+            const size_t p1 = l.find(',', p0);
+            const std::string tok = l.substr(p0, p1 == std::string::npos ? std::string::npos : p1 - p0);
+            if (!tok.empty()) o.devices.push_back(std::stoi(tok));
+            if (p1 == std::string::npos) break;
+            p0 = p1 + 1;
+        }
+        if (o.devices.empty()) throw Error("--devices needs a comma-separated list of GPU ids");
+    } else if (m.count("device")) o.devices.push_back(o.device);
+    o.chunk_reads = std::stoull(opt(m, "chunk-reads", "4096"));
+    MapOutput out = map_reads_multi(ix, reads, o, prefix);
+    fprintf(stderr, "[vgaligner] %llu GPU context(s), %llu batch(es)\n", (unsigned long long)out.n_devices, (unsigned long long)out.n_chunks);
     fprintf(stderr, "[vgaligner] Chaining took: %.0f ms\n", out.ms_map);
     if (o.also_align) fprintf(stderr, "[vgaligner] Alignment took: %.0f ms; Found %llu alignments!\n", out.ms_align, (unsigned long long)out.n_reads);
     if (o.write_console) fputs(o.also_align ? out.alignments_gaf.c_str() : out.chains_gaf.c_str(), stdout);
-    vga_ctx_destroy(ctx);
     return 0;
 }
 
@@ -120,11 +130,13 @@ int map_main(int argc, char **argv)
 
 int main(int argc, char **argv)
 {
+    setenv("VGA_TUNE_MALLOC", "1", 0);  // this process only maps reads: keep the result arrays in the heap (vga_ctx_create)
     try {
         if (argc >= 2 && !strcmp(argv[1], "index")) return index_main(argc, argv);
         if (argc >= 2 && !strcmp(argv[1], "map")) return map_main(argc, argv);
         fprintf(stderr, "vgaligner 0.7 (MI355X build)\nUSAGE:\n  vgaligner index -i <graph.gfa> -k <K> [-o prefix] [-e 100] [-m 100]\n"
-                        "  vgaligner map -i <index> -f <reads.fa|fq> -p abpoa [-o prefix] [-g 1000] [-a 3] [-b 1] [-D -G <graph.gfa>] [-C]\n");
+                        "  vgaligner map -i <index> -f <reads.fa|fq> -p abpoa [-o prefix] [-g 1000] [-a 3] [-b 1] [-D -G <graph.gfa>] [-C]\n"
+                        "                [--devices 0,1,...] [--chunk-reads 4096]\n");
         return 2;
     } catch (const std::exception &e) {
         fprintf(stderr, "vgaligner: %s\n", e.what());

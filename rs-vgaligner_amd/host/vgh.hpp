@@ -112,7 +112,12 @@ struct MapOptions {
     bool also_align = false;             // -D
     uint64_t align_best_n = 1;           // -b
     std::string poa_aligner = "abpoa";   // -p
-    int device = 0;
+    int device = 0;                      // used when `devices` is empty and map_reads is handed a context
+    // Multi-GPU / streaming (not in the reference, which is single-threaded): one context and one host thread per entry of
+    // `devices` (an id may repeat: two contexts on one GPU), each mapping a contiguous slice of the reads balanced by bases, in
+    // chunks of at most `chunk_reads` reads (0 = the whole slice at once) so that host and device memory stay bounded.
+    std::vector<int> devices;
+    uint64_t chunk_reads = 4096;
     bool also_validate = false;          // -v: write validation records (src/validate.rs:18-102, map.rs:186-208)
     std::string validation_path;         // -P
 };
@@ -120,11 +125,26 @@ struct MapOptions {
 struct MapOutput {
     std::string chains_gaf, alignments_gaf, validation;
     uint64_t n_reads = 0, n_aligned = 0, n_anchors = 0, poa_cells = 0;
-    double ms_map = 0, ms_align = 0;
+    double ms_map = 0, ms_align = 0;     // summed over chunks (per device: the maximum over devices)
+    uint64_t n_chunks = 0, n_devices = 0;
 };
 
-// ctx must already hold the uploaded index.  out_prefix == "" writes no files.
+// One [begin, end) range of the read list, the device slot (index into MapOptions::devices) that maps it.
+struct Shard {
+    uint64_t begin, end;
+    uint32_t slot;
+};
+// Contiguous slices balanced by bases, one per device slot (the rule of sharding.py::split_by_bases), each cut into chunks of
+// at most chunk_reads reads.  Shards come in read order; concatenating their outputs reproduces the single-batch output.
+std::vector<Shard> plan_shards(const std::vector<uint64_t> &read_lengths, uint32_t n_slots, uint64_t chunk_reads);
+
+// ctx must already hold the uploaded index: maps everything on that one context, in chunks of opt.chunk_reads.
+// out_prefix == "" writes no files.
 MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt,
                     const std::string &out_prefix);
+// Creates one context per entry of opt.devices (all visible GPUs when empty), uploads the index to each and maps the slices
+// concurrently; GAF order = read order (src/map.rs:123-133, 174-184).
+MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt,
+                          const std::string &out_prefix);
 
 }  // namespace vgh

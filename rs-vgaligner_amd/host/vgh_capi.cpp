@@ -67,6 +67,7 @@ int vgh_map_reads(vga_ctx *ctx, void *h, uint64_t n, const char *const *names, c
         opt.chain_min_n_anchors = chain_min_n_anchors;
         opt.also_align = also_align != 0;
         opt.align_best_n = align_best_n;
+        if (const char *e = getenv("VGH_CHUNK_READS")) opt.chunk_reads = strtoull(e, nullptr, 10);  // (tests)
         MapOutput o = map_reads(ctx, ((IndexBox *)h)->ix, in, opt, out_prefix ? out_prefix : "");
         if (chains_gaf) *chains_gaf = dup_str(o.chains_gaf);
         if (alignments_gaf) *alignments_gaf = dup_str(o.alignments_gaf);
@@ -104,6 +105,41 @@ int64_t vgh_read_seqs_from_file(const char *path, char ***names, char ***seqs)
         *seqs = (char **)malloc((v.size() + 1) * sizeof(char *));
         for (size_t i = 0; i < v.size(); i++) { (*names)[i] = dup_str(v[i].name); (*seqs)[i] = dup_str(v[i].seq); }
         return (int64_t)v.size();
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
+// plan_shards: fills begin/end/slot (capacity cap entries); returns the number of shards (or the number needed when > cap)
+uint64_t vgh_plan_shards(const uint64_t *lengths, uint64_t n, uint32_t n_slots, uint64_t chunk_reads, uint64_t *begin, uint64_t *end,
+                         uint32_t *slot, uint64_t cap)
+{
+    std::vector<uint64_t> len(lengths, lengths + n);
+    const std::vector<Shard> plan = plan_shards(len, n_slots, chunk_reads);
+    for (uint64_t i = 0; i < plan.size() && i < cap; i++) { begin[i] = plan[i].begin; end[i] = plan[i].end; slot[i] = plan[i].slot; }
+    return plan.size();
+}
+
+// map_reads_multi over in-memory reads: one context per entry of devices[] (n_devices == 0: every visible GPU)
+int vgh_map_reads_multi(void *h, uint64_t n, const char *const *names, const char *const *seqs, uint64_t max_gap,
+                        uint64_t chain_min_n_anchors, int also_align, uint64_t align_best_n, const int *devices, uint32_t n_devices,
+                        uint64_t chunk_reads, const char *out_prefix, char **chains_gaf, char **alignments_gaf, uint64_t *n_aligned,
+                        uint64_t *n_chunks)
+{
+    try {
+        std::vector<QuerySequence> in(n);
+        for (uint64_t i = 0; i < n; i++) in[i] = {names[i], seqs[i]};
+        MapOptions opt;
+        opt.max_gap = max_gap;
+        opt.chain_min_n_anchors = chain_min_n_anchors;
+        opt.also_align = also_align != 0;
+        opt.align_best_n = align_best_n;
+        opt.devices.assign(devices, devices + n_devices);
+        opt.chunk_reads = chunk_reads;
+        MapOutput o = map_reads_multi(((IndexBox *)h)->ix, in, opt, out_prefix ? out_prefix : "");
+        if (chains_gaf) *chains_gaf = dup_str(o.chains_gaf);
+        if (alignments_gaf) *alignments_gaf = dup_str(o.alignments_gaf);
+        if (n_aligned) *n_aligned = o.n_aligned;
+        if (n_chunks) *n_chunks = o.n_chunks;
+        return 0;
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 

@@ -8,8 +8,11 @@
 // The reference's debug printing inside the hot loops is not part of the contract and is not reproduced.
 #include "vgh.hpp"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <thread>
 
 namespace vgh {
 
@@ -148,20 +151,53 @@ static void write_file(const std::string &name, const std::string &body)
     if (!o) throw Error("Couldn't write to file " + name);
 }
 
-MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt,
-                    const std::string &out_prefix)
+std::vector<Shard> plan_shards(const std::vector<uint64_t> &len, uint32_t n_slots, uint64_t chunk_reads)
 {
-    if (opt.poa_aligner != "abpoa") {
-        if (opt.poa_aligner == "rspoa") throw Error("the rspoa aligner is not available in the MI355X build yet; use -p abpoa");
-        throw Error("POA Aligner not recognized");  // map_main.rs:67
+    std::vector<Shard> out;
+    if (n_slots == 0) n_slots = 1;
+    const uint64_t n = len.size();
+    uint64_t total = 0;
+    for (uint64_t l : len) total += l;
+    uint64_t start = 0, acc = 0;
+    for (uint32_t slot = 0; slot < n_slots; slot++) {
+        uint64_t end = start;
+        if (slot == n_slots - 1) end = n;
+        else {
+            // (the arithmetic of sharding.py::split_by_bases, in doubles like Python's)
+            const double target = (double)(total * (uint64_t)(slot + 1)) / (double)n_slots;
+            while (end < n && (double)acc + (double)len[end] / 2.0 <= target) { acc += len[end]; end++; }
+        }
+        for (uint64_t c = start; c < end;) {
+            const uint64_t e = chunk_reads ? std::min<uint64_t>(end, c + chunk_reads) : end;
+            out.push_back({c, e, slot});
+            c = e;
+        }
+        start = end;
     }
-    MapOutput out;
-    out.n_reads = inputs.size();
+    return out;
+}
+
+namespace {
+
+struct ChunkOut {
+    std::string chains, aligns;
+    uint64_t n_aligned = 0, n_anchors = 0, poa_cells = 0;
+    double ms_map = 0, ms_align = 0;
+};
+
+// anchors -> chains -> (alignments) of reads [b, e) on one context; the GAF text of exactly those reads
+ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, uint64_t b0, uint64_t e0, const MapOptions &opt)
+{
+    ChunkOut out;
+    const uint64_t n = e0 - b0;
     std::string concat;
-    std::vector<uint64_t> off(inputs.size() + 1, 0);
-    for (size_t i = 0; i < inputs.size(); i++) { concat += inputs[i].seq; off[i + 1] = concat.size(); }
+    std::vector<uint64_t> off(n + 1, 0);
+    uint64_t tot = 0;
+    for (uint64_t i = 0; i < n; i++) tot += inputs[b0 + i].seq.size();
+    concat.reserve(tot);
+    for (uint64_t i = 0; i < n; i++) { concat += inputs[b0 + i].seq; off[i + 1] = concat.size(); }
     vga_batch *b = nullptr;
-    if (vga_batch_create(ctx, concat.data(), off.data(), inputs.size(), &b) != VGA_OK) throw Error(vga_last_error(ctx));
+    if (vga_batch_create(ctx, concat.data(), off.data(), n, &b) != VGA_OK) throw Error(vga_last_error(ctx));
     vga_map_params mp;
     vga_map_default_params(&mp);
     mp.bandwidth = (uint32_t)opt.bandwidth;
@@ -169,43 +205,148 @@ MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequen
     mp.chain_min_n_anchors = (uint32_t)opt.chain_min_n_anchors;
     mp.emit_dp = 0;  // the GAF writers read anchor coordinates and chain membership only
     vga_map_result *m = nullptr;
-    if (vga_map_batch(b, &mp, &m) != VGA_OK) { vga_batch_destroy(b); throw Error(vga_last_error(ctx)); }
+    if (vga_map_batch(b, &mp, &m) != VGA_OK) { const std::string e = vga_last_error(ctx); vga_batch_destroy(b); throw Error(e); }
     out.n_anchors = m->n_anchors;
     out.ms_map = m->ms_total;
     // chains GAF (map.rs:123-145): every chain of every read, in order
-    for (size_t r = 0; r < inputs.size(); r++)
-        for (uint64_t c = m->chain_off[r]; c < m->chain_off[r + 1]; c++) out.chains_gaf += gaf_from_chain(ix, inputs[r], m, r, c);
-    const bool same_file = out_prefix.size() >= 4 && out_prefix.compare(out_prefix.size() - 4, 4, ".gaf") == 0;
-    if (!out_prefix.empty()) write_file(same_file ? out_prefix : out_prefix + "-chains.gaf", out.chains_gaf);
+    for (uint64_t r = 0; r < n; r++)
+        for (uint64_t c = m->chain_off[r]; c < m->chain_off[r + 1]; c++) out.chains += gaf_from_chain(ix, inputs[b0 + r], m, r, c);
     if (opt.also_align) {
         vga_poa_params pp;
         vga_poa_default_params(&pp);
         vga_align_result *a = nullptr;
         if (vga_align_batch(b, m, (uint32_t)opt.align_best_n, &pp, &a) != VGA_OK) {
+            const std::string e = vga_last_error(ctx);
             vga_map_result_free(m); vga_batch_destroy(b);
-            throw Error(vga_last_error(ctx));
+            throw Error(e);
         }
         out.ms_align = a->ms_total;
         out.poa_cells = a->poa_cells;
-        for (size_t r = 0; r < inputs.size(); r++) {
-            out.alignments_gaf += gaf_from_alignment(inputs[r], a, r);
+        for (uint64_t r = 0; r < n; r++) {
+            out.aligns += gaf_from_alignment(inputs[b0 + r], a, r);
             out.n_aligned += a->aligned[r];
-        }
-        // map.rs:174-178: a prefix ending in .gaf makes the alignments overwrite the chains file
-        if (!out_prefix.empty()) write_file(same_file ? out_prefix : out_prefix + "-alignments.gaf", out.alignments_gaf);
-        if (opt.also_validate) {  // map.rs:186-208
-            size_t p0 = 0;
-            while (p0 < out.alignments_gaf.size()) {
-                const size_t p1 = out.alignments_gaf.find('\n', p0);
-                out.validation += validation_record(ix, out.alignments_gaf.substr(p0, p1 - p0), inputs);
-                p0 = p1 + 1;
-            }
-            if (!opt.validation_path.empty()) write_file(opt.validation_path, out.validation);
         }
         vga_align_result_free(a);
     }
     vga_map_result_free(m);
     vga_batch_destroy(b);
+    return out;
+}
+
+void check_aligner(const MapOptions &opt)
+{
+    if (opt.poa_aligner != "abpoa") {
+        if (opt.poa_aligner == "rspoa") throw Error("the rspoa aligner is not available in the MI355X build yet; use -p abpoa");
+        throw Error("POA Aligner not recognized");  // map_main.rs:67
+    }
+}
+
+// file output and validation records of the assembled GAF texts (map.rs:135-139, 174-178, 186-208)
+void finish(MapOutput &out, const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt, const std::string &out_prefix)
+{
+    const bool same_file = out_prefix.size() >= 4 && out_prefix.compare(out_prefix.size() - 4, 4, ".gaf") == 0;
+    if (!out_prefix.empty()) write_file(same_file ? out_prefix : out_prefix + "-chains.gaf", out.chains_gaf);
+    if (!opt.also_align) return;
+    // map.rs:174-178: a prefix ending in .gaf makes the alignments overwrite the chains file
+    if (!out_prefix.empty()) write_file(same_file ? out_prefix : out_prefix + "-alignments.gaf", out.alignments_gaf);
+    if (opt.also_validate) {  // map.rs:186-208
+        size_t p0 = 0;
+        while (p0 < out.alignments_gaf.size()) {
+            const size_t p1 = out.alignments_gaf.find('\n', p0);
+            out.validation += validation_record(ix, out.alignments_gaf.substr(p0, p1 - p0), inputs);
+            p0 = p1 + 1;
+        }
+        if (!opt.validation_path.empty()) write_file(opt.validation_path, out.validation);
+    }
+}
+
+}  // namespace
+
+MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt,
+                    const std::string &out_prefix)
+{
+    check_aligner(opt);
+    MapOutput out;
+    out.n_reads = inputs.size();
+    out.n_devices = 1;
+    std::vector<uint64_t> len(inputs.size());
+    for (size_t i = 0; i < inputs.size(); i++) len[i] = inputs[i].seq.size();
+    for (const Shard &s : plan_shards(len, 1, opt.chunk_reads)) {
+        ChunkOut c = map_chunk(ctx, ix, inputs, s.begin, s.end, opt);
+        out.chains_gaf += c.chains;
+        out.alignments_gaf += c.aligns;
+        out.n_aligned += c.n_aligned; out.n_anchors += c.n_anchors; out.poa_cells += c.poa_cells;
+        out.ms_map += c.ms_map; out.ms_align += c.ms_align;
+        out.n_chunks++;
+    }
+    finish(out, ix, inputs, opt, out_prefix);
+    return out;
+}
+
+MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt, const std::string &out_prefix)
+{
+    check_aligner(opt);
+    // one context per device slot; with no list, every GPU vga_ctx_create accepts
+    std::vector<vga_ctx *> ctxs;
+    auto release = [&]() { for (vga_ctx *c : ctxs) vga_ctx_destroy(c); ctxs.clear(); };
+    std::vector<int> devs = opt.devices;
+    if (devs.empty()) {
+        for (int d = 0; d < 64; d++) {
+            vga_ctx *c = nullptr;
+            if (vga_ctx_create(d, &c) != VGA_OK) break;
+            ctxs.push_back(c);
+        }
+        if (ctxs.empty()) throw Error("no MI355X device available (this build has no CPU path)");
+    } else {
+        for (int d : devs) {
+            vga_ctx *c = nullptr;
+            if (vga_ctx_create(d, &c) != VGA_OK) { release(); throw Error("cannot create a context on device " + std::to_string(d) + " (this build has no CPU path)"); }
+            ctxs.push_back(c);
+        }
+    }
+    const uint32_t n_slots = (uint32_t)ctxs.size();
+    {
+        vga_index_desc d;
+        Index::DescScratch sc;
+        ix.describe(d, sc);
+        for (vga_ctx *c : ctxs)
+            if (vga_index_upload(c, &d) != VGA_OK) { const std::string e = vga_last_error(c); release(); throw Error(e); }
+    }
+    // the library's worker threads (subgraph extraction, CIGAR strings) are per call: share the cores between the slots
+    if (n_slots > 1 && !getenv("VGA_HOST_THREADS")) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        setenv("VGA_HOST_THREADS", std::to_string(std::max(2u, std::min(32u, hw / n_slots))).c_str(), 0);
+    }
+    std::vector<uint64_t> len(inputs.size());
+    for (size_t i = 0; i < inputs.size(); i++) len[i] = inputs[i].seq.size();
+    const std::vector<Shard> plan = plan_shards(len, n_slots, opt.chunk_reads);
+    std::vector<ChunkOut> parts(plan.size());
+    std::vector<std::string> errors(n_slots);
+    std::vector<std::thread> workers;
+    for (uint32_t slot = 0; slot < n_slots; slot++)
+        workers.emplace_back([&, slot]() {
+            try {
+                for (size_t i = 0; i < plan.size(); i++)
+                    if (plan[i].slot == slot) parts[i] = map_chunk(ctxs[slot], ix, inputs, plan[i].begin, plan[i].end, opt);
+            } catch (const std::exception &e) { errors[slot] = e.what(); }
+        });
+    for (std::thread &t : workers) t.join();
+    release();
+    for (const std::string &e : errors)
+        if (!e.empty()) throw Error(e);
+    MapOutput out;
+    out.n_reads = inputs.size();
+    out.n_devices = n_slots;
+    out.n_chunks = plan.size();
+    std::vector<double> ms_map(n_slots, 0.0), ms_align(n_slots, 0.0);
+    for (size_t i = 0; i < plan.size(); i++) {  // read order
+        out.chains_gaf += parts[i].chains;
+        out.alignments_gaf += parts[i].aligns;
+        out.n_aligned += parts[i].n_aligned; out.n_anchors += parts[i].n_anchors; out.poa_cells += parts[i].poa_cells;
+        ms_map[plan[i].slot] += parts[i].ms_map; ms_align[plan[i].slot] += parts[i].ms_align;
+    }
+    for (uint32_t s = 0; s < n_slots; s++) { out.ms_map = std::max(out.ms_map, ms_map[s]); out.ms_align = std::max(out.ms_align, ms_align[s]); }
+    finish(out, ix, inputs, opt, out_prefix);
     return out;
 }
 

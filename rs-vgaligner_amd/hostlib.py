@@ -39,6 +39,12 @@ def load_library():
     L.vgh_validation_records.argtypes = [vp, C.c_char_p, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(vp)]
     L.vgh_read_seqs_from_file.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_char_p))]
     L.vgh_read_seqs_from_file.restype = C.c_int64
+    L.vgh_plan_shards.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_uint32), C.c_uint64]
+    L.vgh_plan_shards.restype = C.c_uint64
+    L.vgh_map_reads_multi.argtypes = [vp, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64,
+                                      C.POINTER(C.c_int), C.c_uint32, C.c_uint64, C.c_char_p, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint64)]
     L.vgh_free.argtypes = [vp]
     _lib = L
     return L
@@ -110,6 +116,25 @@ class HostIndex:
         self.L.vgh_free(ag)
         return c, a, int(na.value)
 
+    def map_reads_multi(self, names: Sequence[str], seqs: Sequence[str], devices: Sequence[int] = (), chunk_reads: int = 4096,
+                        max_gap: int = 1000, chain_min_n_anchors: int = 3, also_align: bool = True, align_best_n: int = 1,
+                        out_prefix: Optional[str] = None) -> Tuple[str, str, int, int]:
+        """vgh::map_reads_multi: one context + host thread per entry of `devices` (all visible GPUs when empty), contiguous
+        base-balanced slices in chunks of chunk_reads; returns (chains GAF, alignments GAF, aligned reads, chunks)"""
+        n = len(seqs)
+        nm = (C.c_char_p * n)(*[s.encode() for s in names])
+        sq = (C.c_char_p * n)(*[s.encode() for s in seqs])
+        dv = (C.c_int * max(1, len(devices)))(*devices)
+        cg, ag, na, nc = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        rc = self.L.vgh_map_reads_multi(self.h, n, nm, sq, max_gap, chain_min_n_anchors, 1 if also_align else 0, align_best_n, dv, len(devices),
+                                        chunk_reads, out_prefix.encode() if out_prefix else None, C.byref(cg), C.byref(ag), C.byref(na), C.byref(nc))
+        if rc != 0:
+            raise HostError(self.L.vgh_last_error().decode())
+        c, a = C.string_at(cg).decode(), C.string_at(ag).decode()
+        self.L.vgh_free(cg)
+        self.L.vgh_free(ag)
+        return c, a, int(na.value), int(nc.value)
+
     def validation_records(self, alignments_gaf: str, names: Sequence[str], seqs: Sequence[str]) -> str:
         """create_validation_records + to_string (src/validate.rs:36-145) for every record of an alignments GAF"""
         n = len(seqs)
@@ -132,6 +157,18 @@ class HostIndex:
             self.close()
         except Exception:
             pass
+
+
+def plan_shards(lengths: Sequence[int], n_slots: int, chunk_reads: int) -> List[Tuple[int, int, int]]:
+    """vgh::plan_shards: [(begin, end, slot)] in read order"""
+    L = load_library()
+    n = len(lengths)
+    ln = (C.c_uint64 * max(1, n))(*lengths)
+    cap = n + n_slots + 1
+    b, e, s = (C.c_uint64 * cap)(), (C.c_uint64 * cap)(), (C.c_uint32 * cap)()
+    m = L.vgh_plan_shards(ln, n, n_slots, chunk_reads, b, e, s, cap)
+    assert m <= cap
+    return [(int(b[i]), int(e[i]), int(s[i])) for i in range(m)]
 
 
 def read_seqs_from_file(path: str) -> List[Tuple[str, str]]:

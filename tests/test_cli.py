@@ -97,3 +97,29 @@ def test_cli_end_to_end_reproduces_golden_gaf(tmp_path):
     # rspoa is the reference's other backend: not built here, refused by name
     p = run(["map", "-i", os.path.join(d, "drb1.idx"), "-f", fq, "-p", "rspoa", "-D", "-G", gfa, "-o", os.path.join(d, "x")], d, ok=False)
     assert "rspoa" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_streams_chunks_over_several_contexts_with_identical_output(tmp_path):
+    """`vgaligner map --devices 0,0 --chunk-reads 300`: two contexts (two host threads) on one GPU, every slice streamed in
+    batches of 300 reads -- the GAF files must equal the single-batch, single-context run byte for byte (GAF order = read
+    order, src/map.rs:123-133,174-184)."""
+    p = pkg()
+    d = str(tmp_path)
+    gfa = os.path.join(DATA, "DRB1-3123.gfa")
+    reads = p.readsim.simulate_reads(gfa, 2000, 2500, 0.03, 0.03, 0.04, seed=4242)
+    fa = os.path.join(d, "r.fa")
+    with open(fa, "w") as f:
+        for r in reads:
+            f.write(">%s\n%s\n" % (r.name, r.seq))
+    run(["index", "-i", gfa, "-k", "11", "-o", os.path.join(d, "drb1")], d)
+    base = ["map", "-i", os.path.join(d, "drb1"), "-f", fa, "-p", "abpoa", "-D", "-G", gfa]
+    one = run(base + ["-o", os.path.join(d, "one"), "--devices", "0", "--chunk-reads", "0"], d)
+    two = run(base + ["-o", os.path.join(d, "two"), "--devices", "0,0", "--chunk-reads", "300"], d)
+    assert "1 GPU context(s), 1 batch(es)" in one.stderr and "2 GPU context(s), 8 batch(es)" in two.stderr
+    for suffix in ("-chains.gaf", "-alignments.gaf"):
+        a, b = open(os.path.join(d, "one" + suffix)).read(), open(os.path.join(d, "two" + suffix)).read()
+        assert a == b and a.count("\n") >= 2000
+    al = open(os.path.join(d, "two-alignments.gaf")).read().splitlines()
+    assert [ln.split("\t")[0] for ln in al] == [r.name for r in reads]
+    assert sum(1 for ln in al if ln.split("\t")[5] != "*") >= 1990

@@ -20,6 +20,30 @@ def test_split_by_bases_is_contiguous_and_balanced():
     assert sp([], 2) == [(0, 0), (0, 0)]
 
 
+def test_cpp_plan_shards_follows_the_same_rule_and_chunks_in_order():
+    """vgh::plan_shards (host/vgh_map.cpp), the slicing the C++ driver `vgaligner map --devices ... --chunk-reads N` uses:
+    slices equal sharding.split_by_bases, chunks tile every slice in read order."""
+    import random
+
+    p = pkg()
+    rng = random.Random(5)
+    cases = [[100] * 10 + [1000] * 2 + [50] * 7, [], [7], [rng.randint(1, 20000) for _ in range(997)], [10000] * 4000]
+    for lens in cases:
+        for world in (1, 2, 3, 8):
+            want = p.sharding.split_by_bases(lens, world)
+            whole = p.hostlib.plan_shards(lens, world, 0)
+            assert [(b, e) for b, e, s in whole if e > b] == [(b, e) for b, e in want if e > b]
+            for chunk in (1, 300, 4096):
+                plan = p.hostlib.plan_shards(lens, world, chunk)
+                assert all(0 < e - b <= chunk for b, e, s in plan)
+                pos = 0
+                for b, e, s in plan:  # contiguous, in read order, inside the slot's slice
+                    assert b == pos and want[s][0] <= b and e <= want[s][1]
+                    pos = e
+                assert pos == len(lens)
+                assert [s for _, _, s in plan] == sorted(s for _, _, s in plan)
+
+
 WORKER = textwrap.dedent("""
     import os, sys, json
     sys.path.insert(0, {root!r})
@@ -33,8 +57,16 @@ WORKER = textwrap.dedent("""
     reads = pkg.readsim.simulate_reads(gfa, 9, 400, 0.03, 0.03, 0.04, seed=123)
     lens = [len(r.seq) for r in reads]
     s, e = pkg.sharding.split_by_bases(lens, world)[rank]
+    # the C++ driver's plan (host/vgh_map.cpp::plan_shards) gives the same slice, cut into chunks of 2 reads here
+    mine = [(b, c) for b, c, slot in pkg.hostlib.plan_shards(lens, world, 2) if slot == rank]
+    assert mine[0][0] == s and mine[-1][1] == e and all(c - b <= 2 for b, c in mine)
     ix = o.Index(o.Graph.from_gfa(gfa), 11)
-    cg, ag, st = o.map_reads(ix, [r.name for r in reads[s:e]], [r.seq for r in reads[s:e]])
+    ag, n_al = "", 0
+    for b, c in mine:  # chunk by chunk, concatenated in read order: what vgh::map_reads_multi does per device slot
+        _, a1, st1 = o.map_reads(ix, [r.name for r in reads[b:c]], [r.seq for r in reads[b:c]])
+        ag += a1
+        n_al += st1["n_aligned_reads"]
+    st = {{"n_aligned_reads": n_al}}
     text = pkg.sharding.gather_in_order(ag, world, rank)
     el, aligned, n = pkg.sharding.reduce_timing(0.5 + rank, st["n_aligned_reads"], e - s, world)
     if rank == 0:
