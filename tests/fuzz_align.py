@@ -22,7 +22,7 @@ for gfa, seeds in ((os.path.join(DATA, "DRB1-3123.gfa"), (101, 102, 103)),):
 if n_reads >= 600:
     import tempfile
     d = tempfile.mkdtemp()
-    hla = os.path.join(d, "hla9.gfa"); p.readsim.config4_graph(DATA, hla)
+    hla = os.path.join(d, "hla19.gfa"); p.readsim.config4_graph(DATA, hla)
     syn = os.path.join(d, "syn.gfa"); p.readsim.synth_pangenome(syn, 80000, seed=5)
     for gfa in (hla, syn, os.path.join(DATA, "DRB1-3123.gfa")):
         ix = o.Index(o.Graph.from_gfa(gfa), 11)

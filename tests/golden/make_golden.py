@@ -28,7 +28,7 @@ def golden_inputs(pkg, tmp_dir):
     drb1 = os.path.join(DATA, "DRB1-3123.gfa")
     syn = os.path.join(tmp_dir, "syn20k.gfa")
     rs.synth_pangenome(syn, 20000, seed=79)
-    hla = os.path.join(tmp_dir, "hla9.gfa")
+    hla = os.path.join(tmp_dir, "hla19.gfa")
     rs.config4_graph(DATA, hla)
     single = [ln.strip() for ln in open(os.path.join(DATA, "single-read-test.fa")) if ln.strip()]
     named = lambda reads: [(r.name, r.seq) for r in reads]
@@ -38,7 +38,7 @@ def golden_inputs(pkg, tmp_dir):
         "drb1_150bp": (drb1, 11, named(rs.simulate_reads(drb1, 6, 150, 0.01, 0.0, 0.0, seed=6))
                        + [("poly_a", "A" * 150), ("with_n", "ACGTN" * 30), ("short", "ACGTACG")]),
         "drb1_2500bp_ont": (drb1, 11, named(rs.simulate_reads(drb1, 2, 2500, 0.03, 0.03, 0.04, seed=7))),
-        "hla9_1200bp_ont": (hla, 11, named(rs.simulate_reads(hla, 4, 1200, 0.03, 0.03, 0.04, seed=8))),
+        "hla19_1200bp_ont": (hla, 11, named(rs.simulate_reads(hla, 6, 1200, 0.03, 0.03, 0.04, seed=8))),
         "syn20k_1500bp_ont": (syn, 11, named(rs.simulate_reads(syn, 3, 1500, 0.03, 0.03, 0.04, seed=9))),
     }
 
