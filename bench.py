@@ -136,6 +136,29 @@ def main():
     elapsed, aligned_all, reads_all = pkg.sharding.reduce_timing(elapsed, last["aligned"], last["n_reads"], world,
                                                                  device="cuda" if world > 1 and not rehearsal else None)
 
+    # measured device-to-device copy rate next to the nominal HBM peak (read + write bytes of 1 GiB copies).  After the timed
+    # region: torch allocations made before it leave less HBM for the library's traceback pool (-10 % on the step)
+    copy_gbs = None
+    if rank == 0 and not os.environ.get("VGA_BENCH_NO_COPY"):
+        try:
+            n_el = 1 << 28  # 2 x 1 GiB of int32
+            a = torch.empty(n_el, dtype=torch.int32, device="cuda").random_(0, 1000)
+            b = torch.empty_like(a)
+            b.copy_(a)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = round(10 * 2 * n_el * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del a, b
+            torch.cuda.empty_cache()
+        except Exception:
+            copy_gbs = None
+
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -169,24 +192,50 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 3),
                 "busy_ms_per_launch": round(busy_per_launch, 3), "concurrency": round(d["ms"] / d["busy_ms"], 3) if d["busy_ms"] > 0 else None,
-                "launches": d["launches"], "algorithmic_bytes_per_launch": int(bytes_per_launch)}
+                "launches": d["launches"], "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                "peak_measured_copy": copy_gbs, "frac_of_measured_copy": round(achieved / copy_gbs, 5) if copy_gbs else None}
+    # the POA kernel's bytes split: compulsory = graph bases + query + one direction byte per band cell
+    # (+ the traceback's reads); value rows = what the node-end rows cost in this implementation (written once, read back once)
+    if dom == "poa_band_dp" and last.get("poa_cells"):
+        comp = (last["poa_rows"] + last["n_reads"] * args.read_len + last["poa_cells"]) * args.steps
+        tot = d["bytes"]
+        roofline["bytes_split"] = {"compulsory_per_launch": int(comp / max(d["launches"], 1)),
+                                   "value_rows_per_launch": int(max(tot - comp, 0) / max(d["launches"], 1)),
+                                   "achieved_compulsory_only": round(comp / (d["busy_ms"] * 1e-3) / 1e9, 2) if d["busy_ms"] > 0 else None,
+                                   "frac_compulsory_only": round(comp / (d["busy_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if d["busy_ms"] > 0 else None}
+        # the ceiling the kernel is actually under: instruction issue.  Counts per band cell come from the committed PMC run
+        # (profiles/instr.json: SQ_INSTS_VALU / SQ_INSTS_SALU of one bench step), the sustainable rate from the microbenchmark
+        # (profiles/r02_valu_issue_microbench.txt: ~0.58 T wave64 VALU instructions/s chip-wide for this instruction mix)
+        ip = os.path.join(ROOT, "profiles", "instr.json")
+        if os.path.exists(ip) and args.workload == "config3":
+            try:
+                ij = json.load(open(ip))
+                cells = last["poa_cells"] * args.steps
+                valu = ij["valu_wave_instr_per_64_cells"] * cells / 64.0
+                rate = valu / (d["busy_ms"] * 1e-3)
+                roofline["valu"] = {"bound": "valu_issue", "achieved": round(rate / 1e9, 1), "peak": ij["peak_Gwaveinst_per_s"], "unit": "G wave64 instr/s",
+                                    "frac": round(rate / 1e9 / ij["peak_Gwaveinst_per_s"], 4), "valu_per_64_cells": ij["valu_wave_instr_per_64_cells"],
+                                    "salu_per_64_cells": ij.get("salu_wave_instr_per_64_cells"), "source": ij.get("source")}
+            except Exception:
+                pass
 
     # ---- CPU baseline: the oracle on a bounded sample of the same reads (N=1 only), run as a child process that never
     # touches the GPU: one core (the reference is single-threaded), and the same code over all host cores
     cpu = None
     cpu_all = None
+    cpu_faithful = None
     if world == 1 and args.cpu_sample > 0 and not map_only:
         import subprocess
         import tempfile
 
-        def run_oracle(ns, nproc):
+        def run_oracle(ns, nproc, faithful=False):
             with tempfile.NamedTemporaryFile("w", suffix=".fa", delete=False) as f:
                 for r in reads[:ns]:
                     f.write(">%s\n%s\n" % (r.name, r.seq))
                 path = f.name
             try:
-                p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), GFA, "11", path, str(nproc)],
-                                   capture_output=True, text=True, timeout=600)
+                p = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), GFA, "11", path, str(nproc)] + (["faithful"] if faithful else []),
+                                   capture_output=True, text=True, timeout=900)
                 if p.returncode != 0:
                     raise RuntimeError(p.stderr[-400:])
                 return json.loads(p.stdout.strip().splitlines()[-1])
@@ -198,6 +247,12 @@ def main():
         cpu = {"value": round(r1["aligned"] / r1["max_worker_s"], 4), "unit": "aligned reads/s", "cores": 1, "kind": "port",
                "sample": f"first {ns} reads of the workload, oracle/libvga_oracle.so (O(log n) k-mer lookup, no debug printing)",
                "seconds": round(r1["max_worker_s"], 2)}
+        # B1 of BASELINE.md section 3: the same port with the reference's cost shape (linear membership scan per query k-mer,
+        # src/index.rs:319; bit-by-bit rank / select, 427-480; whole-sequence clone per node lookup, 516-519), no debug printing
+        nf = min(len(seqs), max(8, ns // 4))
+        rf = run_oracle(nf, 1, faithful=True)
+        cpu_faithful = {"value": round(rf["aligned"] / rf["max_worker_s"], 4), "unit": "aligned reads/s", "cores": 1, "kind": "port",
+                        "sample": f"first {nf} reads of the workload, oracle with og_set_reference_faithful_costs(1)", "seconds": round(rf["max_worker_s"], 2)}
         ncore = max(1, min(os.cpu_count() or 1, 16))  # a GPU box gives one GPU a 16-core share
         nsa = min(len(seqs), max(ns, 4 * ncore))
         ra = run_oracle(nsa, ncore)
@@ -223,10 +278,12 @@ def main():
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "sharding": "reads, replicated index, no collective"},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "cpu_baseline_faithful": cpu_faithful,
         "cpu_baseline_all_cores": cpu_all,
         "reads_per_s": round(reads_all * args.steps / elapsed, 2),
         "per_step": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last.items() if k != "kernels"},
-        "kernels_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in kern.items()},
+        # sum of every launch's own duration: launches of poa_band_dp overlap (three in flight), so this is NOT time per step
+        "kernels_summed_launch_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in kern.items()},
         "kernels_busy_ms_per_step": {k: round(v["busy_ms"] / args.steps, 3) for k, v in kern.items()},
         # algorithmic bytes (per kernel) over the kernel's busy time
         "kernels_algorithmic_gbs": {k: round(v["bytes"] / (v["busy_ms"] * 1e-3) / 1e9, 1) for k, v in kern.items() if v["busy_ms"] > 0 and v["bytes"]},

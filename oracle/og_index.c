@@ -416,12 +416,42 @@ int og_index_graph_kmer(const og_index *ix, uint64_t i, og_graphkmer_view *out)
     return OG_OK;
 }
 
+/* "Reference-faithful" cost mode (baseline B1): the answers never change, but the lookups also do the
+ * work the reference does for them -- the linear Vec::contains over the k-mer keys before the MPHF is asked
+ * (src/index.rs:319), the bit-by-bit rank / inverse rank / select loops (src/index.rs:427-480) and the clone of the whole
+ * linearised sequence per node lookup (src/index.rs:516-519).  Off by default; bench.py's cpu_baseline_faithful leg turns it on. */
+static int og_faithful = 0;
+static volatile uint64_t og_faithful_sink = 0;
+void og_set_reference_faithful_costs(int on) { og_faithful = on; }
+
+static uint64_t og_pack_key(const char *s, uint64_t k)
+{
+    uint64_t v = 0;
+    for (uint64_t i = 0; i < k && i < 21; i++) v = v * 5 + (uint64_t)(s[i] == 'A' ? 0 : s[i] == 'C' ? 1 : s[i] == 'G' ? 2 : s[i] == 'T' ? 3 : 4);
+    return v;
+}
+
 /* index.rs:309-382 */
 size_t og_index_find_positions(const og_index *ix, const char *kmer, size_t kmer_len,
                                const og_kmerpos **out)
 {
     if (out) *out = NULL;
     if (kmer_len != ix->k) return 0; /* index.rs:310-312 */
+    if (og_faithful) { /* kmer_pos_ref.contains(&hash): one u64 per distinct k-mer, scanned from the front (index.rs:319) */
+        static const og_index *cached_ix = NULL;
+        static uint64_t *cached = NULL;
+        if (cached_ix != ix) {
+            free(cached);
+            cached = (uint64_t *)malloc((ix->n_kmers ? ix->n_kmers : 1) * sizeof(uint64_t));
+            for (uint64_t i = 0; i < ix->n_kmers; i++) cached[i] = og_pack_key(ix->kmer_keys + i * ix->k, ix->k);
+            cached_ix = ix;
+        }
+        const uint64_t want = og_pack_key(kmer, ix->k);
+        uint64_t hit = 0;
+        for (uint64_t i = 0; i < ix->n_kmers; i++)
+            if (cached[i] == want) { hit = i + 1; break; }
+        og_faithful_sink += hit;
+    }
     uint64_t lo = 0, hi = ix->n_kmers;
     while (lo < hi) {
         uint64_t mid = (lo + hi) / 2;
@@ -446,6 +476,11 @@ size_t og_index_find_positions(const og_index *ix, const char *kmer, size_t kmer
 uint64_t og_index_bv_rank(const og_index *ix, uint64_t pos)
 {
     if (pos > ix->seq_length) return 0;
+    if (og_faithful) { /* index.rs:427-439: the loop over seq_bv[0..=pos] */
+        uint64_t r = 0;
+        for (uint64_t i = 0; i <= pos; i++) r += ix->seq_bv[i] != 0;
+        og_faithful_sink += r;
+    }
     return ix->rank_prefix[pos];
 }
 
@@ -455,6 +490,11 @@ uint64_t og_index_bv_inverse_rank(const og_index *ix, uint64_t pos)
     if (pos > ix->seq_length) return 0;
     uint64_t start_point = ix->seq_length;
     uint64_t lo = start_point - pos;
+    if (og_faithful) { /* index.rs:443-458: the loop over seq_bv[len-1-pos ..= len-1] */
+        uint64_t r = 0;
+        for (uint64_t i = lo; i <= start_point; i++) r += ix->seq_bv[i] != 0;
+        og_faithful_sink += r;
+    }
     uint64_t total = ix->rank_prefix[start_point];
     return total - (lo > 0 ? ix->rank_prefix[lo - 1] : 0);
 }
@@ -463,6 +503,14 @@ uint64_t og_index_bv_inverse_rank(const og_index *ix, uint64_t pos)
 uint64_t og_index_bv_select(const og_index *ix, uint64_t element_no)
 {
     if (element_no == 0) return 0; /* reference panics */
+    if (og_faithful) { /* index.rs:461-480: walks the bit vector until the element_no-th set bit */
+        uint64_t seen = 0, i = 0;
+        for (; i <= ix->seq_length; i++) {
+            seen += ix->seq_bv[i] != 0;
+            if (seen == element_no) break;
+        }
+        og_faithful_sink += i;
+    }
     if (element_no <= ix->n_nodes + 1) return ix->node_ref[element_no - 1].seq_idx;
     return 0; /* loop falls through with start_pos = 0 */
 }
@@ -495,6 +543,12 @@ size_t og_index_seq_from_handle(const og_index *ix, og_handle h, char *out, size
         ref = ix->seq_rev; start = ix->seq_length - nxt; end = ix->seq_length - cur;
     }
     size_t n = (size_t)(end - start);
+    if (og_faithful) { /* index.rs:516-519: `self.seq_fwd.clone()` (the whole linearisation) before the substring is taken */
+        char *clone = (char *)malloc(ix->seq_length + 1);
+        memcpy(clone, ref, ix->seq_length);
+        og_faithful_sink += (uint64_t)(unsigned char)clone[start < ix->seq_length ? start : 0];
+        free(clone);
+    }
     if (out && n <= cap) memcpy(out, ref + start, n);
     return n;
 }

@@ -179,6 +179,7 @@ def lib():
     L.og_graph_neighbors.argtypes = [vp, u64, C.c_int, C.POINTER(u64), sz]
     L.og_graph_neighbors.restype = sz
 
+    L.og_set_reference_faithful_costs.argtypes = [C.c_int]
     L.og_index_build.argtypes = [vp, u64, u64, u64, C.POINTER(vp)]
     L.og_index_free.argtypes = [vp]
     for name in ("k", "seq_length", "n_nodes", "n_edges", "n_kmers", "n_kmer_pos", "n_graph_kmers"):

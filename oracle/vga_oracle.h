@@ -127,6 +127,8 @@ int og_index_graph_kmer(const og_index *ix, uint64_t i, og_graphkmer_view *out);
 int64_t og_generate_kmers_count(const og_graph *g, uint64_t k, uint64_t edge_max, uint64_t degree_max);
 
 /* index.rs:353-382; returns the number of positions, *out points into the table */
+/* cost mode of bench.py's cpu_baseline_faithful leg (see og_index.c); results are identical either way */
+void og_set_reference_faithful_costs(int on);
 size_t og_index_find_positions(const og_index *ix, const char *kmer, size_t kmer_len,
                                const og_kmerpos **out);
 /* index.rs:427-480, 388-423 */

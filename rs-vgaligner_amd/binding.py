@@ -339,7 +339,7 @@ class Batch:
                        poa_problems=int(r.poa_problems), path_bases=int(np.ctypeslib.as_array(r.path_length, shape=(R,)).sum()) if R else 0,
                        cigar_bytes=int(r.cigar_off[R]) if R else 0,
                        ms_map=float(q.ms_total), ms_probe=float(q.ms_probe), ms_sort=float(q.ms_sort), ms_chain=float(q.ms_chain),
-                       ms_align=float(r.ms_total), ms_subgraph=float(r.ms_subgraph), ms_dp=float(r.ms_dp),
+                       ms_align=float(r.ms_total), ms_subgraph=float(r.ms_subgraph), ms_dp_summed_launches=float(r.ms_dp),
                        ms_traceback=float(r.ms_traceback), kernels=kt_map + kt_aln)
             t3 = _t.perf_counter()
             L.vga_align_result_free(a)

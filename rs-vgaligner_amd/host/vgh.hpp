@@ -117,7 +117,7 @@ struct MapOptions {
     // `devices` (an id may repeat: two contexts on one GPU), each mapping a contiguous slice of the reads balanced by bases, in
     // chunks of at most `chunk_reads` reads (0 = the whole slice at once) so that host and device memory stay bounded.
     std::vector<int> devices;
-    uint64_t chunk_reads = 4096;
+    uint64_t chunk_reads = 16384;
     bool also_validate = false;          // -v: write validation records (src/validate.rs:18-102, map.rs:186-208)
     std::string validation_path;         // -P
 };

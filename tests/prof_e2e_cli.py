@@ -1,0 +1,31 @@
+"""End-to-end wall clock of the product CLI on config 3 (FASTA in -> GAF files out), for DESIGN.md section 5:
+    python tests/prof_e2e_cli.py [n_reads] [extra vgaligner map flags ...]
+Not the bench line: it includes reading the FASTA, the index load + upload, GAF text generation and file output."""
+import json, os, subprocess, sys, tempfile, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
+
+p = ge.load_package()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+extra = sys.argv[2:]
+gfa = os.path.join(ROOT, "tests", "golden", "data", "DRB1-3123.gfa")
+exe = os.path.join(ROOT, "rs-vgaligner_amd", "vgaligner")
+with tempfile.TemporaryDirectory(dir="/tmp") as d:
+    reads = p.readsim.config3_reads(gfa, n)
+    fa = os.path.join(d, "reads.fa")
+    p.readsim.write_fasta(reads, fa)
+    t0 = time.perf_counter()
+    subprocess.check_call([exe, "index", "-i", gfa, "-k", "11", "-o", os.path.join(d, "drb1")])
+    t1 = time.perf_counter()
+    r = subprocess.run([exe, "map", "-i", os.path.join(d, "drb1"), "-f", fa, "-p", "abpoa", "-D", "-G", gfa, "-o", os.path.join(d, "out")] + extra,
+                       capture_output=True, text=True)
+    t2 = time.perf_counter()
+    assert r.returncode == 0, r.stderr
+    al = os.path.join(d, "out-alignments.gaf")
+    aligned = sum(1 for ln in open(al) if ln.split("\t")[5] != "*")
+    print(json.dumps({"reads": n, "aligned": aligned, "index_s": round(t1 - t0, 2), "map_s": round(t2 - t1, 2),
+                      "aligned_reads_per_s_end_to_end": round(aligned / (t2 - t1), 1),
+                      "chains_gaf_mb": round(os.path.getsize(os.path.join(d, "out-chains.gaf")) / 1e6, 1),
+                      "alignments_gaf_mb": round(os.path.getsize(al) / 1e6, 1), "flags": extra, "stderr_tail": r.stderr.strip().splitlines()[-4:]}))
