@@ -208,6 +208,7 @@ __global__ __launch_bounds__(256) void k_anchor_gather_seg(const uint64_t *__res
     }
 }
 
+#ifdef VGA_VARIANTS  // the first form of K3 (18 ds_bpermute per step), superseded by k_chain4: `make variants` builds it for cross-checks
 // ------------------------------------------------------------------------------------------ K3
 // One wavefront per read.  Lane l keeps the most recent sorted anchor j with j % 64 == l in
 // registers, so the look-back window (bandwidth <= 64) is always register-resident; each step
@@ -324,6 +325,8 @@ __global__ __launch_bounds__(VGA_WAVE) void k_chain(
     }
     if (lane == 0) { chain_cnt[r] = nch; chain_words[r] = wpos; }
 }
+
+#endif  // VGA_VARIANTS
 
 // K3, current form.  Same recurrence, window and tie rule as k_chain (kept below the name k_chain for cross-checks,
 // VGA_MAP_CHAIN=old); what changes is the latency of one step of the serial chain, ~4 300 cycles there:
@@ -698,9 +701,13 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
 #define CHAIN_ARGS ws.anchor_off.p, perm, ws.s_qb.p, ws.s_tb.p, ws.s_te.p, ix.k, params->bandwidth, params->max_gap,           \
                    params->chain_min_n_anchors, ws.gap_cost.p, ws.f.p, ws.pred_id.p, ws.pred_pos.p, ws.curr_max.p,         \
                    ws.chain_buf.p, ws.chain_cnt.p, ws.chain_words.p
+#ifdef VGA_VARIANTS
         if (cv && strstr(cv, "old"))
             hipLaunchKernelGGL(k_chain, dim3((unsigned)R), dim3(VGA_WAVE), 0, st, CHAIN_ARGS);
-        else if (gap_bytes <= 16 * 1024)  // (8 KB at the default max_gap; bigger tables stay in HBM)
+        else
+#endif
+        (void)cv;
+        if (gap_bytes <= 16 * 1024)  // (8 KB at the default max_gap; bigger tables stay in HBM)
             hipLaunchKernelGGL(k_chain4<true>, dim3((unsigned)((R + 3) / 4)), dim3(256), gap_bytes, st, (uint32_t)R, CHAIN_ARGS);
         else
             hipLaunchKernelGGL(k_chain4<false>, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, (uint32_t)R, CHAIN_ARGS);

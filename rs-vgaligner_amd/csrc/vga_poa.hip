@@ -617,6 +617,7 @@ __device__ __forceinline__ tb_code tb_decode(int code)
     return c;
 }
 
+#ifdef VGA_VARIANTS  // the one-lane walk (VGA_POA_TB=lane), superseded by poa_traceback_wave
 template <int ENC>
 __global__ __launch_bounds__(64) void k_poa_traceback(
     uint32_t n, const poa_prob *__restrict__ probs, const poa_row *__restrict__ rows,
@@ -690,6 +691,8 @@ __global__ __launch_bounds__(64) void k_poa_traceback(
     if (bad) { outs[pi].status = POA_ST_TRACE; nops = 0; }
     outs[pi].nops = (uint32_t)nops;
 }
+
+#endif  // VGA_VARIANTS
 
 // K4b, cooperative form (the default): one wave per problem.  The walk itself is a chain of dependent reads (row
 // record -> direction byte -> predecessor), two HBM round trips per operation when one lane does it alone.  Here the
@@ -861,8 +864,9 @@ __global__ __launch_bounds__(64) void k_poa_traceback_wave(
     poa_traceback_wave<ENC>(T, (int)threadIdx.x, pb, rows, preds, pool, outs[pi], ops, orow, code_xor, outs[pi].status, outs[pi].row);
 }
 
+#ifdef VGA_VARIANTS  // k_poa_dp_pk (round 1's kernel, incl. its 16-bit and stamp builds), superseded by k_poa_dp_t4: `make variants`
 // ---------------------------------------------------------------------------------------------------------
-// K4, packed form (the default).  Same algorithm and outputs as k_poa_dp_lds; the differences are about
+// K4, packed form (round 1's default).  Same algorithm and outputs as k_poa_dp_lds; the differences are about
 // residency:
 //   * one 32-bit LDS word per column:  (H << 8) | g1 | g2 << G1B   with gk = Ek + min(H - E_k, Ok) (G1B + G2B <= 8
 //     bits for the usual penalties; H needs 23 signed bits), and the query as 4-bit codes indexed by COLUMN
@@ -2122,6 +2126,8 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 6)) void k_poa_dp_pk(
     }
 }
 
+#endif  // VGA_VARIANTS
+
 static inline size_t poa_pk_lds_bytes(uint32_t hg_cols, uint32_t lds_cols, int nt, bool h16 = false)
 {
     const int nw = nt / 64;
@@ -2426,14 +2432,26 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     int g1b_ = 0, g2b_ = 0;
     while ((1 << g1b_) <= params->gap_open1 + params->gap_ext1) g1b_++;
     while ((1 << g2b_) <= params->gap_open2 + params->gap_ext2) g2b_++;
-    const bool packed_k = g1b_ + g2b_ <= 8 && !(force_k && strstr(force_k, "unpacked"));
+#ifdef VGA_VARIANTS
+    const bool pk_built = true;
+#else
+    const bool pk_built = false;  // k_poa_dp_pk / the 16-bit build / the lane traceback only exist in the variants build
+#endif
+    const bool packed_fit = g1b_ + g2b_ <= 8 && !(force_k && strstr(force_k, "unpacked"));
     // k_poa_dp_t4 (vga_poa_t4.hpp), the default: scores scaled by 4 with argmax tags, G bytes 4 g - 1 / 4 g
-    const bool t4_k = packed_k && 4 * (params->gap_open1 + params->gap_ext1) - 1 <= 255 && 4 * (params->gap_open2 + params->gap_ext2) <= 255 &&
+    const bool t4_k = !(force_k && strstr(force_k, "unpacked")) && 4 * (params->gap_open1 + params->gap_ext1) - 1 <= 255 && 4 * (params->gap_open2 + params->gap_ext2) <= 255 &&
                       params->gap_ext1 >= 1 && params->match + params->mismatch >= 0 && params->match + params->mismatch < (1 << 20) &&
-                      !(force_k && (strstr(force_k, "pk") || strstr(force_k, "full"))) && !(getenv("VGA_POA_H16") && atoi(getenv("VGA_POA_H16")) != 0) &&
-                      !getenv("VGA_POA_STAMPS");
+                      !(pk_built && ((force_k && (strstr(force_k, "pk") || strstr(force_k, "full"))) || (getenv("VGA_POA_H16") && atoi(getenv("VGA_POA_H16")) != 0) ||
+                                     getenv("VGA_POA_STAMPS")));
+    const bool packed_k = t4_k || (pk_built && packed_fit);  // a kernel with the LDS column window and the fused traceback
+    // k_poa_dp_pk / k_poa_dp_lds hand pool space out in 1 MiB chunks and assume that a request fits one (k_poa_dp_t4 takes
+    // whole chunks for a larger one): their two wide-row scratch rows (8 B per column) and an unbanded direction row with its
+    // three predecessor planes (4 B per column) must stay below that
+    if (!t4_k && 8ull * (uint64_t)poa_lds_cols(max_q) > POA_CHUNK)
+        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query of %u bases: only k_poa_dp_t4 (default penalties range) handles queries beyond ~131 kbp", max_q);
     // traceback: fused into the packed DP kernel (default), or VGA_POA_TB=wave / lane: a kernel of its own after the DP
-    const bool tb_lane = getenv("VGA_POA_TB") && strstr(getenv("VGA_POA_TB"), "lane");
+    const bool tb_lane = pk_built && getenv("VGA_POA_TB") && strstr(getenv("VGA_POA_TB"), "lane");
+    (void)tb_lane;
     const bool tb_fused = !getenv("VGA_POA_TB") || strstr(getenv("VGA_POA_TB"), "fused");
     const bool arena_wanted = packed_k && tb_fused && !getenv("VGA_POA_STAMPS") && !(getenv("VGA_POA_ARENAS") && atoi(getenv("VGA_POA_ARENAS")) == 0);
     // classic mode: two sub-batches in flight (three are no faster, four overflow their pool quarters).  Arena mode: the
@@ -2586,8 +2604,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             int g1bits = 0, g2bits = 0;
             while ((1 << g1bits) <= P.o1 + P.e1) g1bits++;
             while ((1 << g2bits) <= P.o2 + P.e2) g2bits++;
-            const bool packed = g1bits + g2bits <= 8 && !(force && strstr(force, "unpacked"));
-            const bool t4 = t4_k && packed;
+            const bool t4 = t4_k;
+            const bool packed = t4 || (pk_built && g1bits + g2bits <= 8 && !(force && strstr(force, "unpacked")));
             packed_all = packed_all && packed && !t4;
             t4_any = t4_any || t4;
             // 16-bit row state (3 B per column): default penalties only; problems it gives up on come back with use32
@@ -2675,7 +2693,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 }
 #undef POA_T4_LAUNCH
 #undef POA_T4_ARGS
-            } else if (packed) {
+            }
+#ifdef VGA_VARIANTS
+            else if (packed) {
                 if (getenv("VGA_POA_STAMPS") && nt == 512) {
                     // diagnostic: per-segment cycle shares of the first 64 workgroups (tid 0's wave), printed to stderr
                     static unsigned long long *d_st = nullptr;
@@ -2720,7 +2740,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
 #undef POA_PK_LAUNCH2
 #undef POA_PK_LAUNCH
                 }
-            } else if (nt == 128) {
+            }
+#endif  // VGA_VARIANTS
+            else if (nt == 128) {
                 chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<128, 4>), dim3(nb), dim3(128), lds, st, POA_ARGS);
             } else if (nt == 256) {
@@ -2738,14 +2760,18 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         int t_tb = vga_timer_begin(ctx, "poa_traceback", 0, st);
         if (sub_fused) {
             // the DP kernel's first wave already walked each problem back
-        } else if (tb_lane) {  // VGA_POA_TB=lane: the one-lane-per-problem walk (diagnostic / cross-check)
+        }
+#ifdef VGA_VARIANTS
+        else if (tb_lane) {  // VGA_POA_TB=lane: the one-lane-per-problem walk (diagnostic / cross-check)
             if (sub_t4)
                 hipLaunchKernelGGL(k_poa_traceback<1>, dim3((nb + 63) / 64), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
                                    pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, 0);
             else
                 hipLaunchKernelGGL(k_poa_traceback<0>, dim3((nb + 63) / 64), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
                                    pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, sub_h16 ? 0xC0 : 0);
-        } else if (sub_t4)
+        }
+#endif
+        else if (sub_t4)
             hipLaunchKernelGGL(k_poa_traceback_wave<1>, dim3(nb), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
                                pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, 0);
         else

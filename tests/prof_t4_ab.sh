@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of the POA kernels on config 3: k_poa_dp_t4 (default) vs k_poa_dp_pk (VGA_POA_KERNEL=pk)
+# same-box A/B of the POA kernels on config 3: k_poa_dp_t4 (default) vs k_poa_dp_pk (variants build: make -C rs-vgaligner_amd/csrc variants)
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/${1:-ab}
 mkdir -p $OUT
@@ -10,5 +10,5 @@ print('$1', d['value'], 'reads/s', d['ms_per_step'], 'ms/step; dp busy', d['kern
 VGA_TRACE=1 timeout -k 10 400 python bench.py --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_t4.json 2> $OUT/bench_t4.err || exit 1
 grep -m2 "launch" $OUT/bench_t4.err
 show $OUT/bench_t4.json
-VGA_POA_KERNEL=pk timeout -k 10 400 python bench.py --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_pk.json 2> $OUT/bench_pk.err || exit 1
+VGA_LIB=$GRAFT_REPO_ROOT/rs-vgaligner_amd/libvga_hip_variants.so VGA_POA_KERNEL=pk timeout -k 10 400 python bench.py --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_pk.json 2> $OUT/bench_pk.err || exit 1
 show $OUT/bench_pk.json

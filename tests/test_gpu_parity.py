@@ -265,10 +265,10 @@ _long_ok = pytest.mark.skipif(any(k in os.environ.get("VGA_POA_KERNEL", "") for 
 
 
 @_long_ok
-def test_poa_16bit_row_state_experimental(oracle, ctx, drb1, monkeypatch):
-    """VGA_POA_H16=1: int16 row state relative to a per-row base, packed two-cells-per-instruction interior path.
-    Same results as the oracle; a problem whose scores come near the int16 range is re-run with 32-bit words
-    (unbanded 33 kbp query against a tiny graph: H falls below -30 000 along the first row)."""
+def test_poa_mixed_problem_sizes_and_unbanded_long_query(oracle, ctx, drb1, monkeypatch):
+    """random problems of very different sizes in one batch, and an unbanded 33 kbp query against a tiny graph (H falls below
+    -30 000 along the first row).  With the variants build (VGA_LIB=.../libvga_hip_variants.so) VGA_POA_H16=1 selects round
+    1's 16-bit row state here: a problem whose scores come near the int16 range is re-run with 32-bit words."""
     monkeypatch.setenv("VGA_POA_H16", "1")
     rng = random.Random(4321)
     problems = [_rand_problem(rng, rng.randint(1, 40), 6) for _ in range(60)]
@@ -323,6 +323,39 @@ def test_poa_long_query_beyond_the_lds_window(oracle, ctx):
     g = [q[i:i + 500] for i in range(0, 3000, 500)]
     _check_poa(oracle, ctx, [(g, [(i, i + 1) for i in range(len(g) - 1)], q[:3000] + q[40000:40500]),
                              (["ACGT", "TTGA"], [(0, 1)], q)])
+
+
+@_long_ok
+def test_poa_query_longer_than_a_pool_chunk_of_scratch(oracle, ctx):
+    """140 kbp queries: beyond ~131 kbp the two wide-row scratch rows (12 B per column), a ring of worst-case value
+    rows and a multi-predecessor direction row with its three planes no longer fit one 1 MiB pool chunk each; the allocator
+    of k_poa_dp_t4 takes whole chunks for them.  Tiny graphs keep the oracle cheap: every row spans the whole query."""
+    rng = random.Random(99)
+    q = "".join(rng.choice("ACGT") for _ in range(140000))
+    bubble = (["ACGT", "TT", "GA", "CCAT"], [(0, 1), (0, 2), (1, 3), (2, 3)], q[:70000] + "ACGTTTCCAT" + q[70000:])
+    _check_poa(oracle, ctx, [(["ACGT", "TTGA"], [(0, 1)], q), bubble])
+
+
+def _fallback_problems(rng):
+    return [_rand_problem(rng, rng.randint(1, 40), 6) for _ in range(30)] + [_rand_problem(rng, 60, 60) for _ in range(2)]
+
+
+@pytest.mark.parametrize("env", [{"VGA_POA_ARENAS": "0"}, {"VGA_POA_ARENAS": "0", "VGA_POA_SLOTS": "1"}, {"VGA_POA_KERNEL": "unpacked"},
+                                 {"VGA_POA_TB": "wave"}, {"VGA_POOL_BYTES": "300000000"}, {"VGA_POA_SUB": "7"}, {"VGA_POA_WINDOW": "256"}],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_poa_paths_the_library_can_fall_back_to(oracle, ctx, drb1, monkeypatch, env):
+    """the configurations poa_run selects by itself when it has to -- classic pool instead of arenas (problems too large for
+    an arena), k_poa_dp_lds (gap penalties beyond the byte range of k_poa_dp_t4), a traceback kernel of its own, a pool so
+    small that sub-batches are re-queued, tiny sub-batches, a narrow LDS window (HBM detour of wide rows) -- forced through
+    their environment switches and held to the same parity"""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = random.Random(31)
+    _check_poa(oracle, ctx, _fallback_problems(rng))
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    n = 2 if env.get("VGA_POA_KERNEL") == "unpacked" else 3
+    _check_align(oracle, ctx, ix, pkg().readsim.simulate_reads(DRB1, n, 2500, 0.03, 0.03, 0.04, seed=12))
 
 
 def test_batch_outlives_its_context(drb1, oracle):
