@@ -27,6 +27,7 @@
 #include "vga_poa_internal.hpp"
 
 #include <algorithm>
+#include <cstddef>
 #include <type_traits>
 #include <chrono>
 #include <thread>
@@ -42,6 +43,7 @@
 #define POA_ST_NOALN 2
 #define POA_ST_TRACE 3
 #define POA_ST_RANGE 4  // 16-bit storage: a score came near the representable range, the problem is re-run in 32 bits
+#define POA_ST_WIDE 5   // k_poa_dp_w1: a row wider than its register file (or a query with non-ACGT characters): re-run with k_poa_dp_t4
 
 struct poa_prob {
     uint64_t node0;  // first entry of the node table (entry 0 of a problem is the virtual source)
@@ -64,11 +66,21 @@ struct poa_prob {
 struct poa_row {          // per DP row, 48 B
     int32_t beg, end;     // band
     uint64_t doff, voff;  // direction row / value row in the pool
-    uint32_t pred, npred; // predecessor row or predecessor-list slice; npred != 0 only on the first row of a node
     int32_t lmax, rmax;   // leftmost / rightmost column of the row maximum
-    int32_t base, hmax;   // 16-bit storage (k_poa_dp_pk<.., H16>): the row's values are stored relative to `base`;
-                          // hmax = the row maximum (absolute).  0 / unused otherwise.
+    // the last four words form one aligned 16-byte group: k_poa_rowprep fills them for k_poa_dp_w1, which reads them with a
+    // single scalar load per row
+    uint32_t pred, npred; // predecessor row or predecessor-list slice; npred != 0 only on the first row of a node
+    int32_t base, hmax;   // k_poa_dp_pk<.., H16>: the row's values are stored relative to `base`, hmax = the row maximum.
+                          // k_poa_dp_w1: base = graph bases after this row on the longest path to the sink ("remain"),
+                          // hmax = static flags of the row (POA_RF_*), both written by k_poa_rowprep
 };
+static_assert(sizeof(poa_row) == 48 && offsetof(poa_row, pred) == 32, "poa_row layout");
+#define POA_RF_FIRST 1u    // first base of a node (other than the source)
+#define POA_RF_LAST 2u     // last base of a node
+#define POA_RF_SINK 4u     // ... of a node without successors: the row feeds the sink
+#define POA_RF_KEEP 8u     // its value row is read more than POA_RING_SPAN nodes ahead: kept outside the ring
+#define POA_RF_FAR 16u     // a predecessor is not the row directly above
+                           // bits 8..10: code of the row's base (A C G T other), bits 16..23: number of predecessors
 
 struct poa_out {          // per problem, 56 B
     int32_t score;
@@ -2144,6 +2156,7 @@ static inline size_t poa_lds_bytes(uint32_t lds_cols, int nt)
 }
 
 #include "vga_poa_t4.hpp"
+#include "vga_poa_w1.hpp"
 
 // ============================================================================================ host
 namespace {
@@ -2432,6 +2445,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     int g1b_ = 0, g2b_ = 0;
     while ((1 << g1b_) <= params->gap_open1 + params->gap_ext1) g1b_++;
     while ((1 << g2b_) <= params->gap_open2 + params->gap_ext2) g2b_++;
+    const bool tb_fused_early = !getenv("VGA_POA_TB") || strstr(getenv("VGA_POA_TB"), "fused");
 #ifdef VGA_VARIANTS
     const bool pk_built = true;
 #else
@@ -2444,6 +2458,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                       !(pk_built && ((force_k && (strstr(force_k, "pk") || strstr(force_k, "full"))) || (getenv("VGA_POA_H16") && atoi(getenv("VGA_POA_H16")) != 0) ||
                                      getenv("VGA_POA_STAMPS")));
     const bool packed_k = t4_k || (pk_built && packed_fit);  // a kernel with the LDS column window and the fused traceback
+    // k_poa_dp_w1 (vga_poa_w1.hpp): one wave per problem, row state in registers; default penalties, queries whose codes fit its LDS
+    const bool def_pen_k = params->gap_open1 == 4 && params->gap_ext1 == 2 && params->gap_open2 == 24 && params->gap_ext2 == 1;
+    const bool w1_k = t4_k && def_pen_k && tb_fused_early && max_q <= 16000 && !(force_k && strstr(force_k, "t4")) &&
+                      (force_k ? strstr(force_k, "w1") != nullptr : getenv("VGA_POA_W1") != nullptr);
     // k_poa_dp_pk / k_poa_dp_lds hand pool space out in 1 MiB chunks and assume that a request fits one (k_poa_dp_t4 takes
     // whole chunks for a larger one): their two wide-row scratch rows (8 B per column) and an unbanded direction row with its
     // three predecessor planes (4 B per column) must stay below that
@@ -2671,8 +2689,17 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                  W.d_next.p + slot, half_pool, S.d_outs.p, lds_cols
 #define POA_PK_ARGS POA_ARGS, hg_cols, win_mask, g1bits, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr), \
                     (arena ? n_arenas : 0u), arena_size, W.d_arena_ctr.p, W.d_arena_flag.p
+            const bool w1 = w1_k && t4 && !use32 && arena;  // (problems it hands back -- POA_ST_WIDE -- come again with use32 set)
             sub_t4 = t4;
-            if (t4) {
+            if (w1) {
+                const size_t lds1 = poa_w1_lds_bytes(mq);
+                if (tr.on) fprintf(stderr, "[vga-trace] poa: launch %u problems, k_poa_dp_w1 (one wave per problem), LDS %zu B\n", nb, lds1);
+                hipLaunchKernelGGL(k_poa_rowprep, dim3(nb), dim3(256), 0, st, S.d_probs.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_rows.p);
+                chk(hipFuncSetAttribute((const void *)k_poa_dp_w1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+                hipLaunchKernelGGL(k_poa_dp_w1, dim3(nb), dim3(64), lds1, st, S.d_probs.p, S.d_q.p, S.d_preds.p, P, S.d_rows.p, pool_base,
+                                   W.d_next.p + slot, half_pool, S.d_outs.p, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr),
+                                   (arena ? n_arenas : 0u), arena_size, W.d_arena_ctr.p, W.d_arena_flag.p, (const uint4 *)S.d_rows.p);
+            } else if (t4) {
 #define POA_T4_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, P, S.d_rows.p, pool_base, W.d_next.p + slot, half_pool,   \
                     S.d_outs.p, lds_cols, hg_cols, win_mask, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr),       \
                     (arena ? n_arenas : 0u), arena_size, W.d_arena_ctr.p, W.d_arena_flag.p
@@ -2789,7 +2816,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         const uint32_t p = order[i];
         poa_item &it = out[p];
         const poa_out &ho = S.h_outs.p[i - i0];
-        if (ho.status == POA_ST_RANGE || ho.status == POA_ST_POOL) return;  // re-run later (16-bit range / arena too small)
+        if (ho.status == POA_ST_RANGE || ho.status == POA_ST_POOL || ho.status == POA_ST_WIDE) return;  // re-run later
         it.ok = ho.status == POA_ST_OK ? 1 : 0;
         it.score = ho.score;
         it.n_cells = ho.cells;
@@ -2950,11 +2977,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         }
         // problems the 16-bit kernel stopped (a score near the int16 range) run again with 32-bit words
         for (uint64_t i = cur.i0; i < cur.i1; i++)
-            if (S.h_outs.p[i - cur.i0].status == POA_ST_RANGE) retry32.push_back(order[i]);
+            if (S.h_outs.p[i - cur.i0].status == POA_ST_RANGE || S.h_outs.p[i - cur.i0].status == POA_ST_WIDE) retry32.push_back(order[i]);
         if (todo.empty() && inflight.empty() && !retry32.empty()) {
             const uint64_t a = order.size();
             for (uint32_t p : retry32) order.push_back(p);
-            if (tr.on) fprintf(stderr, "[vga-trace] poa: %zu problems re-run with 32-bit rows\n", retry32.size());
+            if (tr.on) fprintf(stderr, "[vga-trace] poa: %zu problems handed back (16-bit range / too wide for the register kernel): re-run\n", retry32.size());
             retry32.clear();
             todo.push_back({a, order.size(), true, n_arenas != 0});
         }
@@ -2973,7 +3000,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             parallel_for(cnt, [&](uint64_t t) { post_one(S, a0, a0 + t); });
             for (uint64_t i = cur.i0; i < cur.i1; i++) {
                 const poa_out &ho = S.h_outs.p[i - cur.i0];
-                if (ho.status == POA_ST_RANGE || ho.status == POA_ST_POOL) continue;
+                if (ho.status == POA_ST_RANGE || ho.status == POA_ST_POOL || ho.status == POA_ST_WIDE) continue;
                 all_cells += ho.cells; all_vcells += ho.vcells; all_ops += ho.nops;
                 all_rows += G[order[i]].N; all_q += G[order[i]].qlen;
             }

@@ -67,13 +67,13 @@ __device__ __forceinline__ int t4_max3(int a, int b, int c)
 __device__ __forceinline__ int t4_shr1_max(int v, int pre)
 {
     int r = pre;
-    asm("v_max_i32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v), "v"(pre));
+    asm("s_nop 1\n\tv_max_i32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v), "v"(pre));  // (s_nop: the compiler does not see that %1 is read through DPP)
     return r;
 }
 __device__ __forceinline__ int t4_shr1_mov(int v, int first)  // lanes 1..63: v of the lane below; lane 0: first
 {
     int r = first;
-    asm("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
+    asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(v));
     return r;
 }
 

@@ -336,6 +336,23 @@ def test_poa_query_longer_than_a_pool_chunk_of_scratch(oracle, ctx):
     _check_poa(oracle, ctx, [(["ACGT", "TTGA"], [(0, 1)], q), bubble])
 
 
+def test_poa_one_wave_per_problem_kernel(oracle, ctx, drb1, monkeypatch):
+    """VGA_POA_W1=1: k_poa_dp_w1 (vga_poa_w1.hpp) -- one wave per problem, the row state in 144 hand-managed vector registers
+    addressed through gfx9's VGPR index mode.  Parity-green but 2.3x slower than k_poa_dp_t4 on config 3 (a single wave per
+    problem is latency-bound at two waves per SIMD), hence opt-in.  Problems it hands back
+    (POA_ST_WIDE: a band beyond 6 144 columns, non-ACGT query bases) are re-run by k_poa_dp_t4."""
+    monkeypatch.setenv("VGA_POA_W1", "1")
+    rng = random.Random(77)
+    problems = [_rand_problem(rng, rng.randint(1, 40), 6) for _ in range(40)] + [_rand_problem(rng, 60, 60) for _ in range(3)]
+    problems.append((["ACGT", "TTGA"], [(0, 1)], "".join(rng.choice("ACGT") for _ in range(9000))))  # 9 001 columns: handed back
+    problems.append((["AC", "GT", "NN"], [(0, 1), (1, 2)], "ACNGTNN"))
+    _check_poa(oracle, ctx, problems)
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    _check_align(oracle, ctx, ix, pkg().readsim.simulate_reads(DRB1, 4, 2500, 0.03, 0.03, 0.04, seed=13))
+    _check_align(oracle, ctx, ix, pkg().readsim.config3_reads(DRB1, 2))
+
+
 def _fallback_problems(rng):
     return [_rand_problem(rng, rng.randint(1, 40), 6) for _ in range(30)] + [_rand_problem(rng, 60, 60) for _ in range(2)]
 
