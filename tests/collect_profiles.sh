@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box into gpurun_out/prof_<tag>/ (copy the summaries into profiles/ afterwards):
 #   1. bench.py plain (the driver's command), 2. the same under rocprofv3 --kernel-trace --stats,
-#   3./4. PMC passes FETCH_SIZE and WRITE_SIZE (separate runs, kernel-trace only), one bench step each.
+#   3./4. PMC passes FETCH_SIZE and WRITE_SIZE (separate runs, kernel-trace only), one bench step each,
+#   5. a PMC pass with the instruction counters (SQ_INSTS_*), one bench step.
 # usage (on the GPU box, via gpurun):  bash tests/collect_profiles.sh v7
 set -e
 TAG=${1:-vX}
@@ -17,4 +18,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_poa_dp" -d $OUT/pmc_$c -o pmc --output-format csv -- python3 $REPO/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
   echo "pmc $c done"
 done
+# instruction counters of the same step (the issue-rate fraction in bench.py's roofline.valu comes from these)
+timeout -k 10 500 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_BANK_CONFLICT --kernel-trace --kernel-include-regex "k_poa_dp" -d $OUT/pmc_INSTS -o pmc --output-format csv -- python3 $REPO/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/bench_pmc_INSTS.json 2> $OUT/pmc_INSTS.err
+echo "pmc INSTS done"
 find $OUT -name "*.csv" | head -20

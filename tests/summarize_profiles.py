@@ -1,16 +1,18 @@
 """Turns gpurun_out/prof_<tag>/ (tests/collect_profiles.sh) into the committed summaries under profiles/:
-r01_<tag>_bench_10k.json, r01_<tag>_bench_10k_under_rocprof.json, r01_<tag>_kernel_stats.csv, r01_<tag>_pmc_poa_dp.txt
-and profiles/traffic.json (HBM bytes per step of the dominant kernel: FETCH_SIZE x 2 + WRITE_SIZE, in KiB, per
-MI355X_MICROARCH.md's gfx950 note).   usage: python tests/summarize_profiles.py v8"""
+<round>_<tag>_bench_10k.json, ..._bench_10k_under_rocprof.json, ..._kernel_stats.csv, ..._pmc_poa_dp.txt,
+profiles/traffic.json (HBM bytes per step of the dominant kernel: FETCH_SIZE x 2 + WRITE_SIZE, in KiB, per
+MI355X_MICROARCH.md's gfx950 note) and profiles/instr.json (SQ_INSTS_VALU / SQ_INSTS_SALU per 64 band cells).
+usage: python tests/summarize_profiles.py v12 [r02]"""
 import csv, json, os, shutil, sys
 
 tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
-shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"), os.path.join(dst, f"r01_{tag}_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"r01_{tag}_bench_10k.json"))
-shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"r01_{tag}_bench_10k_under_rocprof.json"))
+shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"), os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{rnd}_{tag}_bench_10k.json"))
+shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{rnd}_{tag}_bench_10k_under_rocprof.json"))
 last = lambda f: json.loads(open(os.path.join(src, f)).read().strip().splitlines()[-1])
 out, vals, launches, alg = [], {}, 0, 0
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -25,18 +27,45 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     vals[c] = tot
     b = last(f"bench_pmc_{c}.json")
     launches, alg = b["roofline"]["launches"], b["roofline"]["launches"] * b["roofline"]["algorithmic_bytes_per_launch"]
-open(os.path.join(dst, f"r01_{tag}_pmc_poa_dp.txt"), "w").write("\n".join(out) + "\n")
+open(os.path.join(dst, f"{rnd}_{tag}_pmc_poa_dp.txt"), "w").write("\n".join(out) + "\n")
 hbm = (vals["FETCH_SIZE"] * 2 + vals["WRITE_SIZE"]) * 1024
 t = {"kernel": "poa_band_dp", "reads": 10000, "read_len": 10000, "fetch_size_kib_per_step": vals["FETCH_SIZE"],
      "write_size_kib_per_step": vals["WRITE_SIZE"],
      "correction": "gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
      "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace --kernel-include-regex k_poa_dp -- python3 bench.py "
-               f"--steps 1 --warmup 0 --cpu-sample 0 (tests/collect_profiles.sh {tag}; raw rows in profiles/r01_{tag}_pmc_poa_dp.txt)",
+               f"--steps 1 --warmup 0 --cpu-sample 0 (tests/collect_profiles.sh {tag}; raw rows in profiles/{rnd}_{tag}_pmc_poa_dp.txt)",
      "launches_in_pmc_step": launches, "hbm_bytes_per_step": hbm, "algorithmic_bytes_per_step": alg, "ratio": hbm / alg,
      "note": "bench.py divides hbm_bytes_per_step by its own launches per step; the traceback is fused into the DP kernel, so its reads of the direction bytes are included"}
 json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 b, br = last("bench.json"), last("bench_under_rocprof.json")
-ks = next(r for r in csv.DictReader(open(os.path.join(src, "kt", "kt_kernel_stats.csv"))) if "k_poa_dp_pk" in r["Name"])
+ks = max((r for r in csv.DictReader(open(os.path.join(src, "kt", "kt_kernel_stats.csv"))) if "k_poa_dp" in r["Name"]), key=lambda r: float(r["TotalDurationNs"]))
 print("bench", b["value"], b["ms_per_step"], b["roofline"]["achieved"], b["roofline"]["frac"], "cpu", b["cpu_baseline"]["value"], b["cpu_baseline_all_cores"]["value"])
 print("under rocprof", br["value"], "avg_launch_ms", br["roofline"]["avg_launch_ms"], "rocprof avg ms", float(ks["AverageNs"]) / 1e6, "calls", ks["Calls"])
 print("traffic ratio", t["ratio"], "launches", launches)
+
+# instruction counters -> profiles/instr.json (read by bench.py for roofline.valu)
+ip = os.path.join(src, "pmc_INSTS", "pmc_counter_collection.csv")
+if os.path.exists(ip):
+    import collections
+    tot, kname = collections.Counter(), ""
+    lines = ["# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_BANK_CONFLICT "
+             "--kernel-trace --kernel-include-regex k_poa_dp -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0", "dispatch,kernel,counter,value"]
+    for r in csv.DictReader(open(ip)):
+        tot[r["Counter_Name"]] += float(r["Counter_Value"])
+        kname = r["Kernel_Name"].split("(")[0]
+        lines.append(",".join([r["Dispatch_Id"], r["Kernel_Name"][:32].replace(",", ";"), r["Counter_Name"], r["Counter_Value"]]))
+    for k, v in sorted(tot.items()): lines.append(f"# sum {k} = {v}")
+    open(os.path.join(dst, f"{rnd}_{tag}_pmc_insts.txt"), "w").write("\n".join(lines) + "\n")
+    cells = last("bench_pmc_INSTS.json")["poa_cells_per_step"] if "poa_cells_per_step" in last("bench_pmc_INSTS.json") else None
+    old = json.load(open(os.path.join(dst, "instr.json")))
+    cells = cells or old["cells_per_step"]
+    ij = {"kernel": kname, "valu_wave_instr_per_64_cells": round(tot["SQ_INSTS_VALU"] * 64 / cells, 1),
+          "salu_wave_instr_per_64_cells": round(tot["SQ_INSTS_SALU"] * 64 / cells, 1),
+          "lds_wave_instr_per_64_cells": round(tot["SQ_INSTS_LDS"] * 64 / cells, 1), "cells_per_step": cells,
+          "sq_insts_valu_per_step": tot["SQ_INSTS_VALU"], "sq_insts_salu_per_step": tot["SQ_INSTS_SALU"],
+          "peak_Gwaveinst_per_s": old["peak_Gwaveinst_per_s"],
+          "source": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ... --kernel-trace --kernel-include-regex k_poa_dp -- python3 bench.py --steps 1 --warmup 0 "
+                    f"--cpu-sample 0 (tests/collect_profiles.sh {tag}; raw rows in profiles/{rnd}_{tag}_pmc_insts.txt); peak: tests/microbench/valu_issue.hip, "
+                    "profiles/r02_valu_issue_microbench.txt (v_max_i32 / VOP3 / DPP / SDWA / v_pk_* at 6 waves per SIMD: 0.53-0.60 T/s)"}
+    json.dump(ij, open(os.path.join(dst, "instr.json"), "w"), indent=1)
+    print("instr", ij["valu_wave_instr_per_64_cells"], ij["salu_wave_instr_per_64_cells"])
