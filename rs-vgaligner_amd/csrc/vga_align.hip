@@ -6,10 +6,11 @@
 //   find_nodes_edges_for_abpoa .. src/align.rs:670-724
 //   create_align_safe ........... src/align.rs:202        -> vga_poa_batch (vga_poa.hip)
 //   generate_alignment .......... src/align.rs:1096-1168  (fields only; the GAF text is host code)
-// The subgraph extraction is light integer work over the index's CSR arrays (src/index.rs:388-606)
-// and runs on host threads while the GPU is busy with the DP of the previous call; moving it to the
-// device is listed under "next" in DESIGN.md.  The ./subgraphs/*.gfa export side effect of
-// align.rs:104-111 is a debugging aid and is not reproduced.
+// The subgraph extraction and the POA node tables are built on the GPU (vga_subgraph.hip: one wave per chain over the
+// index's CSR arrays in HBM); the host only reduces each chain's anchors to their extremes -- the same pass that fixes
+// the launch order.  VGA_SUBGRAPH=host selects the host-thread walk below instead (build_subgraph + poa_prepare), which
+// the GPU tests use as a second opinion.  The ./subgraphs/*.gfa export side effect of align.rs:104-111 is a debugging
+// aid and is not reproduced.
 #include "vga_common.hpp"
 #include "vga_poa_internal.hpp"
 
@@ -71,6 +72,15 @@ struct index_view {
             std::reverse(out.begin(), out.end());
         }
     }
+    // dna.rs:19-33
+    static char complement(char c)
+    {
+        switch (c) {
+        case 'a': return 't'; case 'c': return 'g'; case 't': return 'a'; case 'g': return 'c'; case 'u': return 'a';
+        case 'A': return 'T'; case 'C': return 'G'; case 'T': return 'A'; case 'G': return 'C'; case 'U': return 'A';
+        default: return 'N';
+        }
+    }
     // seq_from_handle (src/index.rs:503-533); the reverse strand is derived as dna.rs:19-33 does
     void append_seq(handle_t h, std::string &out) const
     {
@@ -78,15 +88,7 @@ struct index_view {
         uint32_t s = ix.node_start[id - 1], e = ix.node_start[id];
         if (!(h & 1)) out.append(ix.seq_fwd.data() + s, e - s);
         else
-            for (uint32_t i = e; i-- > s;) {
-                char c = ix.seq_fwd[i], r;
-                switch (c) {
-                case 'a': r = 't'; break; case 'c': r = 'g'; break; case 't': r = 'a'; break; case 'g': r = 'c'; break;
-                case 'u': r = 'a'; break; case 'A': r = 'T'; break; case 'C': r = 'G'; break; case 'T': r = 'A'; break;
-                case 'G': r = 'C'; break; case 'U': r = 'A'; break; default: r = 'N';
-                }
-                out.push_back(r);
-            }
+            for (uint32_t i = e; i-- > s;) out.push_back(complement(ix.seq_fwd[i]));
     }
 };
 
@@ -278,18 +280,26 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
 
     // ---- subgraphs: built by the host threads on request, one sub-batch ahead of the GPU (see poa_feed).  The launch
     // order is fixed up front from the span of each chain on the linearised graph.
-    std::vector<subgraph_t> SG(n);
+    const char *sg_env = getenv("VGA_SUBGRAPH");
+    const bool on_device = !(sg_env && strstr(sg_env, "host"));
+    std::vector<subgraph_t> SG(on_device ? 0 : n);
     poa_feed feed;
     feed.views.resize(n);
     std::vector<double> proxy(n, 0.0);
+    std::vector<sg_desc> descs(on_device ? n : 0);
+    std::vector<uint64_t> q_src(on_device ? n : 0);
     vga_parallel_for(n, [&](uint64_t p) {
         const uint64_t r = prob_read[p], c = prob_chain[p];
         const uint64_t a0 = m->anchor_off[r];
-        uint32_t lo = 0xFFFFFFFFu, hi = 0;
+        uint32_t lo = 0xFFFFFFFFu, hi = 0, pmin = 0xFFFFFFFFu, pmax = 0;
         for (uint64_t t = m->chain_anchor_off[c]; t < m->chain_anchor_off[c + 1]; t++) {
             const uint64_t ai = a0 + m->chain_anchor_idx[t];
             lo = std::min(lo, m->target_begin[ai]);
             hi = std::max(hi, m->target_end[ai]);
+            // smallest / largest position over the anchors' begins and inclusive ends (align.rs:286-308; chain.rs:65-70)
+            const uint32_t s = m->target_begin[ai], e = m->target_end[ai] - 1;
+            pmin = std::min(pmin, std::min(s, e));
+            pmax = std::max(pmax, std::max(s, e));
         }
         const uint32_t ql = (uint32_t)(b->read_off[r + 1] - b->read_off[r]);
         // footprint ~ rows x mean band width.  Rows: the chain's span on the linearised graph plus what the extension
@@ -302,13 +312,37 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         const double rows = (double)(hi > lo ? hi - lo : 0) + 1.6 * uncovered;
         proxy[p] = rows * (650.0 + 0.3 * std::max(0.0, 0.85 * rows - (double)ql));
         feed.views[p] = {nullptr, nullptr, 0, nullptr, nullptr, 0, b->reads.data() + b->read_off[r], ql};
+        if (on_device) {
+            const uint64_t fa = a0 + m->chain_anchor_idx[c0], la = a0 + m->chain_anchor_idx[c1 - 1];
+            descs[p] = {pmin, pmax, m->query_begin[fa], m->target_begin[fa], m->query_begin[la], m->target_end[la], ql, 0u};
+            q_src[p] = b->read_off[r];
+        }
     });
     feed.proxy = proxy.data();
     double sub_ms = 0;
     const unsigned n_thr = std::max(1u, vga_host_threads(n));
     std::vector<scratch_t> scratch(n_thr);
-    for (auto &sc : scratch) sc.best.assign((size_t)(ctx->index.n_nodes + 2) * 2, 0);
-    feed.prepare = [&](const uint32_t *ids, uint64_t cnt) {
+    if (!on_device)
+        for (auto &sc : scratch) sc.best.assign((size_t)(ctx->index.n_nodes + 2) * 2, 0);
+    sg_store store;
+    index_view iv_all(ctx->index);
+    if (on_device) {
+        vga_timers_reset(ctx);
+        feed.keep_timers = true;
+        auto ta = std::chrono::steady_clock::now();
+        const int rc = sg_prepare(ctx, descs.data(), q_src.data(), n, b->d_reads, store);
+        if (rc != VGA_OK) return rc;
+        sub_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
+        feed.dev = &store;
+        // base `off` of the node-th handle of problem p (seq_from_handle, src/index.rs:503-533)
+        feed.row_base = [&](uint64_t p, uint32_t node, uint32_t off) -> char {
+            const handle_t h = store.h_handles[store.off[p].node0 + node];
+            const uint32_t id = h >> 1, s = ctx->index.node_start[id - 1], e = ctx->index.node_start[id];
+            return (h & 1) ? iv_all.complement(ctx->index.seq_fwd[e - 1 - off]) : ctx->index.seq_fwd[s + off];
+        };
+        tr.mark("subgraphs on the GPU");
+    }
+    if (!on_device) feed.prepare = [&](const uint32_t *ids, uint64_t cnt) {
         auto ta = std::chrono::steady_clock::now();
         const unsigned nt = std::min<uint64_t>(n_thr, cnt);
         std::vector<std::thread> th;
@@ -397,7 +431,8 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         const poa_item &it = items[p];
         uint64_t o = res->path_off[r];
         for (size_t t = 0; t < it.gnodes.size(); t++)
-            if (t == 0 || it.gnodes[t] != it.gnodes[t - 1]) res->path_handles[o++] = SG[p].handles[it.gnodes[t]];  // align.rs:1120-1123
+            if (t == 0 || it.gnodes[t] != it.gnodes[t - 1])  // align.rs:1120-1123
+                res->path_handles[o++] = on_device ? store.h_handles[store.off[p].node0 + it.gnodes[t]] : SG[p].handles[it.gnodes[t]];
         res->path_length[r] = (uint32_t)it.rows.size();
         res->path_start[r] = it.start_off;
         res->path_end[r] = it.end_off;
@@ -410,12 +445,12 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     for (uint64_t p = 0; p < n; p++) {
         res->poa_rows += items[p].n_rows; res->poa_cells += items[p].n_cells; res->poa_value_cells += items[p].n_vcells;
     }
-    res->ms_subgraph = (float)sub_ms;  // host threads, overlapped with the GPU after the first sub-batch
+    res->ms_subgraph = (float)sub_ms;  // GPU kernels before the first DP launch (VGA_SUBGRAPH=host: host threads, overlapped with the GPU)
     res->ms_dp = tm.ms_dp;
     res->ms_traceback = tm.ms_tb;
     res->ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     tr.mark("assemble records");
-    if (tr.on) {
+    if (tr.on && !on_device) {
         fprintf(stderr, "[vga-trace] align: subgraph thread time: range %.1f ms, extension %.1f ms, node strings %.1f ms, edges %.1f ms\n",
                 g_ns_range.exchange(0) / 1e6, g_ns_extend.exchange(0) / 1e6, g_ns_seq.exchange(0) / 1e6, g_ns_edges.exchange(0) / 1e6);
     }

@@ -29,7 +29,11 @@ struct vga_dev_index {
     uint64_t table_entries = 0;
     uint2 *d_pos = nullptr;
     uint64_t n_pos_words = 0;
-    // host copies used by the subgraph extraction (src/align.rs:267-724)
+    // the graph itself for the device-side subgraph extraction (vga_subgraph.hip): forward sequence, node starts
+    // (n_nodes + 1), per node the first edge / the number of incoming edges, the edge lists as packed handles
+    char *d_seq_fwd = nullptr;
+    uint32_t *d_node_start = nullptr, *d_edge_idx = nullptr, *d_edges_to = nullptr, *d_edges = nullptr;
+    // host copies (the host-thread extraction VGA_SUBGRAPH=host, path handles and cs strings of the results)
     std::vector<char> seq_fwd;
     std::vector<uint32_t> node_start;  // n_nodes+1
     std::vector<uint32_t> edge_idx;    // n_nodes+1
@@ -69,6 +73,8 @@ struct vga_ctx {
     void (*map_ws_free)(void *) = nullptr;
     void *poa_ws = nullptr;
     void (*poa_ws_free)(void *) = nullptr;
+    void *sg_ws = nullptr;
+    void (*sg_ws_free)(void *) = nullptr;
     // live read batches: vga_ctx_destroy releases their device memory and detaches them, so a batch handle may be
     // destroyed after its context
     std::vector<struct vga_batch *> batches;

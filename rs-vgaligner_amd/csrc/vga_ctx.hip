@@ -74,6 +74,11 @@ static void vga_index_release(vga_dev_index &ix)
 {
     if (ix.d_table) (void)hipFree(ix.d_table);
     if (ix.d_pos) (void)hipFree(ix.d_pos);
+    if (ix.d_seq_fwd) (void)hipFree(ix.d_seq_fwd);
+    if (ix.d_node_start) (void)hipFree(ix.d_node_start);
+    if (ix.d_edge_idx) (void)hipFree(ix.d_edge_idx);
+    if (ix.d_edges_to) (void)hipFree(ix.d_edges_to);
+    if (ix.d_edges) (void)hipFree(ix.d_edges);
     ix = vga_dev_index();
 }
 
@@ -91,6 +96,7 @@ extern "C" void vga_ctx_destroy(vga_ctx *ctx)
     }
     if (ctx->map_ws && ctx->map_ws_free) ctx->map_ws_free(ctx->map_ws);
     if (ctx->poa_ws && ctx->poa_ws_free) ctx->poa_ws_free(ctx->poa_ws);
+    if (ctx->sg_ws && ctx->sg_ws_free) ctx->sg_ws_free(ctx->sg_ws);
     vga_index_release(ctx->index);
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -296,6 +302,19 @@ static int vga_index_upload_impl(vga_ctx *ctx, const vga_index_desc *d)
     VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_pos, pos.size() * sizeof(uint2)));
     VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_table, table.data(), entries * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_pos, pos.data(), pos.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    // the graph for the device-side subgraph extraction
+    const size_t nn1 = (size_t)d->n_nodes + 1;
+    VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_seq_fwd, d->seq_length + 16));
+    VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_node_start, nn1 * sizeof(uint32_t)));
+    VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_edge_idx, nn1 * sizeof(uint32_t)));
+    VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_edges_to, nn1 * sizeof(uint32_t)));
+    VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_edges, (d->n_edges + 1) * sizeof(uint32_t)));
+    VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_seq_fwd, ix.seq_fwd.data(), d->seq_length, hipMemcpyHostToDevice, ctx->stream));
+    VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_node_start, ix.node_start.data(), nn1 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_edge_idx, ix.edge_idx.data(), nn1 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_edges_to, ix.edges_to.data(), nn1 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    if (d->n_edges)
+        VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_edges, ix.edges.data(), d->n_edges * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     VGA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     ix.loaded = true;
     return VGA_OK;

@@ -2158,6 +2158,28 @@ static inline size_t poa_lds_bytes(uint32_t lds_cols, int nt)
 #include "vga_poa_t4.hpp"
 #include "vga_poa_w1.hpp"
 
+// One workgroup per staged problem: copies its node table, predecessor rows, sink rows, bases and query from the device
+// store of vga_subgraph.hip (and the batch's reads) to where this sub-batch's poa_prob says they are.
+// ids: per staged problem its index in the store and its number of predecessor entries
+__global__ __launch_bounds__(256) void k_sg_gather(const uint32_t *__restrict__ ids, const poa_prob *__restrict__ probs, const sg_off *__restrict__ offs,
+                                                   const uint4 *__restrict__ s_ntab, const uint32_t *__restrict__ s_preds,
+                                                   const uint32_t *__restrict__ s_sinks, const char *__restrict__ s_seq, const char *__restrict__ reads,
+                                                   uint4 *ntab, uint32_t *preds, uint32_t *sinks, char *seq, char *q)
+{
+    const uint32_t p = ids[2 * blockIdx.x], n_preds = ids[2 * blockIdx.x + 1];
+    const poa_prob pb = probs[blockIdx.x];
+    const sg_off of = offs[p];
+    const int tid = threadIdx.x;
+    const uint4 *a = s_ntab + of.node0 + p;
+    for (uint32_t i = (uint32_t)tid; i < pb.n_nodes; i += 256) ntab[pb.node0 + i] = a[i];
+    for (uint32_t i = (uint32_t)tid; i < n_preds; i += 256) preds[pb.pred0 + i] = s_preds[of.pred0 + i];
+    for (uint32_t i = (uint32_t)tid; i < pb.n_sink; i += 256) sinks[pb.sink0 + i] = s_sinks[of.sink0 + i];
+    const uint32_t *sw = (const uint32_t *)(s_seq + of.seq0);  // (seq0 is a multiple of 4 on both sides)
+    uint32_t *dw = (uint32_t *)(seq + pb.seq0);
+    for (uint32_t i = (uint32_t)tid; i < (pb.N + 3) / 4; i += 256) dw[i] = sw[i];
+    for (uint32_t i = (uint32_t)tid; i < pb.qlen; i += 256) q[pb.q0 + i] = reads[of.q_src + i];
+}
+
 // ============================================================================================ host
 namespace {
 
@@ -2169,6 +2191,8 @@ struct poa_prep {
     std::vector<uint4> ntab;            // node table incl. the source entry
     std::vector<uint32_t> preds, sinks; // row ids
     std::vector<uint32_t> first_row;    // per input node
+    uint32_t n_ntab = 0, n_preds = 0, n_sinks = 0;  // entries of the three lists (with a device store the vectors stay empty)
+    const uint32_t *first_row_p = nullptr;          // first rows, n_ntab - 1 entries (host graphs: first_row.data())
 };
 
 // Node-level graph description: first rows, predecessor rows in edge-list order, remain of the last base of each
@@ -2243,6 +2267,8 @@ void poa_prepare(const poa_view &v, poa_prep &g)
     }
     g.longest = longest;
     g.ntab[0] = make_uint4(0u, 1u, (uint32_t)longest, 0u);  // the virtual source: row 0, remain = longest path
+    g.n_ntab = (uint32_t)g.ntab.size(); g.n_preds = (uint32_t)g.preds.size(); g.n_sinks = (uint32_t)g.sinks.size();
+    g.first_row_p = g.first_row.data();
     g.ok = true;
 }
 
@@ -2250,14 +2276,14 @@ void poa_prepare(const poa_view &v, poa_prep &g)
 struct poa_slot {
     vga_dbuf<poa_prob> d_probs;
     vga_dbuf<uint4> d_ntab;
-    vga_dbuf<uint32_t> d_seq32, d_preds, d_sink, d_orow;
+    vga_dbuf<uint32_t> d_seq32, d_preds, d_sink, d_orow, d_ids;
     vga_dbuf<uint8_t> d_ops;
     vga_dbuf<poa_row> d_rows;
     vga_dbuf<poa_out> d_outs;
     vga_dbuf<char> d_q;
     vga_hbuf<poa_prob> h_probs;
     vga_hbuf<uint4> h_ntab;
-    vga_hbuf<uint32_t> h_seq32, h_preds, h_sink;
+    vga_hbuf<uint32_t> h_seq32, h_preds, h_sink, h_ids;
     vga_hbuf<char> h_q;
     // results come back into one of two sets, alternating per use of the slot: the host is still reading set A of the
     // sub-batch that just finished when the next sub-batch on this slot is enqueued (it will write set B)
@@ -2321,7 +2347,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         params->gap_ext1 < 0 || params->gap_ext2 < 0 || params->gap_open1 + params->gap_ext1 > 255 ||
         params->gap_open2 + params->gap_ext2 > 255)
         return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "gap penalties: open + extend must be in 0..255 (one byte per gap state)");
-    vga_timers_reset(ctx);
+    if (!feed.keep_timers) vga_timers_reset(ctx);
     if (n == 0) return VGA_OK;
     uint32_t max_q = 0;
     for (uint64_t p = 0; p < n; p++) {
@@ -2374,7 +2400,16 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         if (feed.prepare) feed.prepare(ids.data(), ids.size());
         parallel_for(ids.size(), [&](uint64_t t) {
             const uint32_t p = ids[t];
-            poa_prepare(views[p], G[p]);
+            if (feed.dev) {
+                // the device store holds the graph: only its sizes come to the host
+                const sg_sum &sm = feed.dev->sum[p];
+                poa_prep &g = G[p];
+                g.ok = !(sm.flags & 1u) && sm.n_nodes > 0 && views[p].qlen < (1u << 24);
+                g.N = sm.N; g.qlen = views[p].qlen; g.longest = (int32_t)sm.longest; g.life = sm.life;
+                g.n_ntab = sm.n_nodes + 1; g.n_preds = sm.n_preds; g.n_sinks = sm.n_sinks;
+                g.first_row_p = feed.dev->h_first_row + feed.dev->off[p].node0;
+            } else
+                poa_prepare(views[p], G[p]);
             // footprint in the pool: a direction byte per cell plus the value-row ring (packed kernel)
             if (G[p].ok) {
                 estw[p] = est_width(p);
@@ -2569,44 +2604,63 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             const poa_prep &g = G[p];
             pb.node0 = tot_nodes; pb.pred0 = tot_preds; pb.sink0 = tot_sink; pb.q0 = tot_q; pb.ops0 = tot_ops; pb.row0 = tot_rows;
             pb.seq0 = tot_seq;
-            pb.n_sink = (uint32_t)g.sinks.size(); pb.qlen = g.qlen; pb.N = g.N; pb.n_nodes = (uint32_t)g.ntab.size(); pb.ring_rows = g.life + 1;
+            pb.n_sink = g.n_sinks; pb.qlen = g.qlen; pb.N = g.N; pb.n_nodes = g.n_ntab; pb.ring_rows = g.life + 1;
             pb.flags = arena && (est[p] * W.pool_scale + 3.0 * (double)POA_CHUNK) * 1.1 > (double)arena_size ? 1u : 0u;
             pb.pad = 0;
             pb.w = params->wb < 0 ? g.qlen : (uint32_t)((int64_t)params->wb + (int64_t)(params->wf * (double)g.qlen));
-            tot_nodes += g.ntab.size();
-            tot_preds += g.preds.size();
-            tot_sink += g.sinks.size();
+            tot_nodes += g.n_ntab;
+            tot_preds += g.n_preds;
+            tot_sink += g.n_sinks;
             tot_q += g.qlen;
             tot_ops += (uint64_t)g.N + g.qlen + 2;
             tot_rows += (uint64_t)g.N + 1;
             tot_seq += ((uint64_t)g.N + 3) & ~3ull;
             out[p].n_rows = g.N;
         }
-        chk(S.h_probs.reserve(nb)); chk(S.h_ntab.reserve(tot_nodes)); chk(S.h_seq32.reserve(tot_seq / 4 + 1));
-        chk(S.h_preds.reserve(tot_preds + 1)); chk(S.h_sink.reserve(tot_sink + 1)); chk(S.h_q.reserve(tot_q + 1));
+        const bool dev = feed.dev != nullptr;
+        chk(S.h_probs.reserve(nb));
+        if (dev) chk(S.h_ids.reserve(2 * (size_t)nb));
+        else {
+            chk(S.h_ntab.reserve(tot_nodes)); chk(S.h_seq32.reserve(tot_seq / 4 + 1));
+            chk(S.h_preds.reserve(tot_preds + 1)); chk(S.h_sink.reserve(tot_sink + 1)); chk(S.h_q.reserve(tot_q + 1));
+        }
         chk(O.h_ops.reserve(tot_ops)); chk(O.h_orow.reserve(tot_ops)); chk(O.h_outs.reserve(nb));
         chk(S.d_probs.reserve(nb)); chk(S.d_ntab.reserve(tot_nodes)); chk(S.d_seq32.reserve(tot_seq / 4 + 1));
         chk(S.d_preds.reserve(tot_preds + 1)); chk(S.d_sink.reserve(tot_sink + 1)); chk(S.d_q.reserve(tot_q + 1));
         chk(S.d_rows.reserve(tot_rows)); chk(S.d_outs.reserve(nb)); chk(S.d_ops.reserve(tot_ops)); chk(S.d_orow.reserve(tot_ops));
+        if (dev) chk(S.d_ids.reserve(2 * (size_t)nb));
         if (launch_err != hipSuccess) return {i0, i0, 0.0, slot, 0};
-        parallel_for(nb, [&](uint64_t t) {
-            const uint32_t p = order[i0 + t];
-            const poa_prob &pb = probs[p];
-            const poa_prep &g = G[p];
-            S.h_probs.p[t] = pb;
-            memcpy(S.h_ntab.p + pb.node0, g.ntab.data(), g.ntab.size() * sizeof(uint4));
-            if (!g.preds.empty()) memcpy(S.h_preds.p + pb.pred0, g.preds.data(), g.preds.size() * 4);
-            if (!g.sinks.empty()) memcpy(S.h_sink.p + pb.sink0, g.sinks.data(), g.sinks.size() * 4);
-            // node strings of one problem are contiguous in the view
-            memcpy((char *)S.h_seq32.p + pb.seq0, views[p].nodes + views[p].node_off[0], g.N);
-            if (g.qlen) memcpy(S.h_q.p + pb.q0, views[p].query, g.qlen);
-        });
-        chk(hipMemcpyAsync(S.d_probs.p, S.h_probs.p, nb * sizeof(poa_prob), hipMemcpyHostToDevice, st));
-        chk(hipMemcpyAsync(S.d_ntab.p, S.h_ntab.p, tot_nodes * sizeof(uint4), hipMemcpyHostToDevice, st));
-        chk(hipMemcpyAsync(S.d_seq32.p, S.h_seq32.p, tot_seq, hipMemcpyHostToDevice, st));
-        chk(hipMemcpyAsync(S.d_preds.p, S.h_preds.p, tot_preds * 4, hipMemcpyHostToDevice, st));
-        chk(hipMemcpyAsync(S.d_sink.p, S.h_sink.p, tot_sink * 4, hipMemcpyHostToDevice, st));
-        chk(hipMemcpyAsync(S.d_q.p, S.h_q.p, tot_q, hipMemcpyHostToDevice, st));
+        if (dev) {
+            // the graphs are in the device store: one workgroup per problem copies its pieces into this slot's buffers
+            for (uint32_t t = 0; t < nb; t++) {
+                const uint32_t p = order[i0 + t];
+                S.h_probs.p[t] = probs[p]; S.h_ids.p[2 * t] = p; S.h_ids.p[2 * t + 1] = G[p].n_preds;
+            }
+            chk(hipMemcpyAsync(S.d_probs.p, S.h_probs.p, nb * sizeof(poa_prob), hipMemcpyHostToDevice, st));
+            chk(hipMemcpyAsync(S.d_ids.p, S.h_ids.p, 2 * (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            const sg_store &D = *feed.dev;
+            hipLaunchKernelGGL(k_sg_gather, dim3(nb), dim3(256), 0, st, S.d_ids.p, S.d_probs.p, D.d_off, D.d_ntab, D.d_preds, D.d_sinks, D.d_seq, D.d_reads,
+                               S.d_ntab.p, S.d_preds.p, S.d_sink.p, (char *)S.d_seq32.p, S.d_q.p);
+        } else {
+            parallel_for(nb, [&](uint64_t t) {
+                const uint32_t p = order[i0 + t];
+                const poa_prob &pb = probs[p];
+                const poa_prep &g = G[p];
+                S.h_probs.p[t] = pb;
+                memcpy(S.h_ntab.p + pb.node0, g.ntab.data(), g.ntab.size() * sizeof(uint4));
+                if (!g.preds.empty()) memcpy(S.h_preds.p + pb.pred0, g.preds.data(), g.preds.size() * 4);
+                if (!g.sinks.empty()) memcpy(S.h_sink.p + pb.sink0, g.sinks.data(), g.sinks.size() * 4);
+                // node strings of one problem are contiguous in the view
+                memcpy((char *)S.h_seq32.p + pb.seq0, views[p].nodes + views[p].node_off[0], g.N);
+                if (g.qlen) memcpy(S.h_q.p + pb.q0, views[p].query, g.qlen);
+            });
+            chk(hipMemcpyAsync(S.d_probs.p, S.h_probs.p, nb * sizeof(poa_prob), hipMemcpyHostToDevice, st));
+            chk(hipMemcpyAsync(S.d_ntab.p, S.h_ntab.p, tot_nodes * sizeof(uint4), hipMemcpyHostToDevice, st));
+            chk(hipMemcpyAsync(S.d_seq32.p, S.h_seq32.p, tot_seq, hipMemcpyHostToDevice, st));
+            chk(hipMemcpyAsync(S.d_preds.p, S.h_preds.p, tot_preds * 4, hipMemcpyHostToDevice, st));
+            chk(hipMemcpyAsync(S.d_sink.p, S.h_sink.p, tot_sink * 4, hipMemcpyHostToDevice, st));
+            chk(hipMemcpyAsync(S.d_q.p, S.h_q.p, tot_q, hipMemcpyHostToDevice, st));
+        }
         chk(hipMemsetAsync(W.d_next.p + slot, 0, sizeof(unsigned long long), st));
         int t_dp = vga_timer_begin(ctx, "poa_band_dp", 0, st);
         {
@@ -2827,7 +2881,17 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         const uint8_t *po = S.h_ops.p + pb.ops0;
         const uint32_t *pr = S.h_orow.p + pb.ops0;
         const char *q = views[p].query;
-        const char *bases = views[p].nodes + views[p].node_off[0];  // row r is bases[r - 1]
+        // base of graph row r (rows ascend along the path): bases[r - 1] of the host graph, or -- device store -- the
+        // index sequence via the node the row belongs to
+        const char *bases = feed.dev ? nullptr : views[p].nodes + views[p].node_off[0];
+        const uint32_t *frow = g.first_row_p;
+        const size_t nv = (size_t)g.n_ntab - 1;
+        size_t vcur = 0;
+        auto base_of = [&](uint32_t r) -> char {
+            if (bases) return bases[r - 1];
+            while (vcur + 1 < nv && frow[vcur + 1] <= r) vcur++;
+            return feed.row_base(p, (uint32_t)vcur, r - frow[vcur]);
+        };
         const uint32_t nops = ho.nops;
         std::string &cg = it.cigar, &cs = it.cs;
         cs = "cs:Z:";
@@ -2849,7 +2913,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             for (uint32_t x = t2; x > u; x--) {
                 const uint32_t idx = x - 1;
                 if (op == 0) {
-                    const char gb = bases[pr[idx] - 1], qb = q[qi++];
+                    const char gb = base_of(pr[idx]), qb = q[qi++];
                     aligned++;
                     if (gb == qb) eq_run++;
                     else {
@@ -2860,7 +2924,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 } else if (op == 1) {
                     cs.push_back(lower(q[qi++]));
                 } else {
-                    cs.push_back(lower(bases[pr[idx] - 1]));
+                    cs.push_back(lower(base_of(pr[idx])));
                     it.rows.push_back(pr[idx]);
                 }
             }
@@ -2871,14 +2935,13 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         // rows ascend along the path: merge-walk the node table to label them
         it.gnodes.resize(it.rows.size());
         size_t v = 0;
-        const size_t nv = g.first_row.size();
         for (size_t t = 0; t < it.rows.size(); t++) {
-            while (v + 1 < nv && g.first_row[v + 1] <= it.rows[t]) v++;
+            while (v + 1 < nv && frow[v + 1] <= it.rows[t]) v++;
             it.gnodes[t] = (uint32_t)v;
         }
         if (!it.rows.empty()) {
-            it.start_off = it.rows.front() - g.first_row[it.gnodes.front()];
-            it.end_off = it.rows.back() - g.first_row[it.gnodes.back()] + 1;
+            it.start_off = it.rows.front() - frow[it.gnodes.front()];
+            it.end_off = it.rows.back() - frow[it.gnodes.back()] + 1;
         }
     };
     // Software pipeline.  `todo` holds the launch-order ranges still to be enqueued (a sub-batch that overflowed its pool

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "vga_common.hpp"
+#include "vga_subgraph.hpp"
 
 // one create_align_safe(nodes, edges, query, Global) problem, by reference
 struct poa_view {
@@ -38,10 +39,17 @@ struct poa_timing {
 // set the graph part of a view (nodes, edges) is filled on request, for the listed problems, shortly before they are
 // staged -- poa_run calls it while earlier sub-batches are on the GPU -- and `proxy` (one value per problem, larger
 // = bigger) fixes the launch order up front.  Without `prepare` every view is complete and the order is by footprint.
+// With `dev` set the graphs never exist on the host: the node tables, predecessor lists, sinks and bases of all problems
+// already sit in the device store sg_prepare filled (vga_subgraph.hip) and are gathered into a sub-batch's buffers device to
+// device; the queries come from the batch's device copy of the reads.  `row_base(p, node, off)` then gives the base of a
+// node's row for the cs strings (the index sequence, via the problem's handle list).
 struct poa_feed {
     std::vector<poa_view> views;
     std::function<void(const uint32_t *ids, uint64_t cnt)> prepare;
     const double *proxy = nullptr;
+    const sg_store *dev = nullptr;
+    std::function<char(uint64_t p, uint32_t node, uint32_t off)> row_base;
+    bool keep_timers = false;  // the caller has reset the context's kernel timers and recorded some of its own
 };
 
 // Runs every problem on the GPU (sub-batched to fit the pool).  Returns VGA_OK or a negative VGA_ERR_*.

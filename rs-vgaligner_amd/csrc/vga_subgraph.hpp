@@ -1,0 +1,55 @@
+// vga_subgraph.hpp -- device-side chain -> subgraph -> POA node table (vga_subgraph.hip), as vga_align.hip and poa_run see it.
+//
+// Replaces, on the GPU, the host walk of find_range_chain / extend_range_chain_2 / find_nodes_edges_for_abpoa
+// (src/align.rs:267-402, 523-665, 670-724) and the node-table construction poa_prepare does for host graphs.
+#pragma once
+
+#include <cstdint>
+
+#include "vga_common.hpp"
+
+// one chain, as the host hands it over (the extremes of its anchors; the reduction over the anchors is the one the launch
+// order needs anyway)
+struct sg_desc {
+    uint32_t pmin, pmax;        // smallest / largest forward position among the anchors' begins and inclusive ends
+    uint32_t q_first, t_first;  // first anchor: query_begin, target_begin
+    uint32_t q_last, te_last;   // last anchor: query_begin, target_end (exclusive)
+    uint32_t qlen, pad;
+};
+
+// what the kernels report per problem
+struct sg_sum {
+    uint32_t n_nodes;  // handles of the subgraph
+    uint32_t N;        // rows = graph bases
+    uint32_t n_preds, n_sinks;
+    uint32_t wlo, whi;  // words of the handle bitmap that hold set bits
+    uint32_t longest;   // graph bases on the longest source-sink path
+    uint32_t life;      // largest edge span (in nodes) among the nodes that use the value-row ring
+    uint32_t flags;     // bit 0: malformed for the POA kernels (in-degree > 255, too many rows)
+    uint32_t pad[3];
+};
+
+// where a problem's pieces live in the store
+struct sg_off {
+    uint64_t node0;  // handles / first_row: node0 .. node0 + n_nodes;  node table: node0 + problem index (one source entry each)
+    uint64_t pred0, sink0, seq0;
+    uint64_t q_src;  // first base of the query in the batch's device copy of the reads
+};
+
+// the prepared problems of one vga_align_batch call (device store + what the host needs of it)
+struct sg_store {
+    uint64_t n = 0;
+    const sg_sum *sum = nullptr;     // host, n entries
+    const sg_off *off = nullptr;     // host, n entries
+    const sg_off *d_off = nullptr;   // device copy
+    const uint4 *d_ntab = nullptr;
+    const uint32_t *d_preds = nullptr, *d_sinks = nullptr;
+    const char *d_seq = nullptr;
+    const char *d_reads = nullptr;
+    const uint32_t *h_handles = nullptr, *h_first_row = nullptr;  // host copies (pinned), indexed from off[p].node0
+};
+
+// Runs the extraction for n chains on ctx->stream and waits for it.  `store` points into the context's workspace and stays
+// valid until the next call.  Returns VGA_OK or a negative VGA_ERR_*.
+int sg_prepare(vga_ctx *ctx, const sg_desc *descs, const uint64_t *q_src, uint64_t n, const char *d_reads, sg_store &store);
+

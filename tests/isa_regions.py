@@ -1,4 +1,4 @@
-"""Static instruction counts of k_poa_dp_pk<NT> between the POA_MARK region markers (diagnostics only).
+"""Static instruction counts of k_poa_dp_t4<NT, true> between the POA_MARK region markers (diagnostics only).
 
     python3 tests/isa_regions.py [NT]
 """
@@ -11,7 +11,7 @@ subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-ar
                        "-S", "--cuda-device-only", "-I", os.path.dirname(src), src, "-o", out], stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
 # the default instantiation: compile-time penalties, 4 columns per lane, 32-bit row state
-start = next(i for i, l in enumerate(lines) if l.startswith("_Z11k_poa_dp_pkILi%sELb0ELb1ELi4ELb0EE" % nt))
+start = next(i for i, l in enumerate(lines) if l.startswith("_Z11k_poa_dp_t4ILi%sELb1EE" % nt))
 end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
 region = "prologue"
 cnt = collections.OrderedDict()

@@ -234,6 +234,26 @@ def test_align_config4_merged_hla_sample(oracle, ctx, config4_gfa):
     _check_align(oracle, ctx, ix, pick)
 
 
+def test_subgraphs_from_host_threads_match_the_device_kernels(oracle, ctx, drb1, config4_gfa, monkeypatch):
+    """VGA_SUBGRAPH=host: find_range_chain / extend_range_chain_2 / find_nodes_edges_for_abpoa and the POA node tables on host
+    threads (the round-1 path) instead of k_sg_mark / k_sg_emit -- same records as the oracle and as the device path, on
+    DRB1-3123 and on the merged HLA graph (whose loci keep links between opposite strands)"""
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    reads = pkg().readsim.simulate_reads(DRB1, 6, 2500, 0.03, 0.03, 0.04, seed=14) + pkg().readsim.config2_reads(DRB1, 30)
+    dev = _check_align(oracle, ctx, ix, reads)
+    monkeypatch.setenv("VGA_SUBGRAPH", "host")
+    host = _check_align(oracle, ctx, ix, reads)
+    assert dev.cigar == host.cigar and dev.path_handles.tolist() == host.path_handles.tolist() and dev.poa_cells == host.poa_cells
+    ix4 = oracle.Index(oracle.Graph.from_gfa(config4_gfa), 11)
+    upload_oracle_index(ctx, ix4)
+    reads4 = pkg().readsim.config3_reads(config4_gfa, 12)
+    host4 = _check_align(oracle, ctx, ix4, reads4)
+    monkeypatch.delenv("VGA_SUBGRAPH")
+    dev4 = _check_align(oracle, ctx, ix4, reads4)
+    assert dev4.cigar == host4.cigar and dev4.path_handles.tolist() == host4.path_handles.tolist()
+
+
 def test_align_config5_synthetic_pangenome_sample(oracle, ctx, config5_small_gfa):
     """BASELINE config #5 generator (SNP bubble / 100 bp, indel bubble / 1 kbp, 32 bp nodes) at 60 kbp"""
     ix = oracle.Index(oracle.Graph.from_gfa(config5_small_gfa), 11)
