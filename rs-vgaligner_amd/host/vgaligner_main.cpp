@@ -118,6 +118,7 @@ int map_main(int argc, char **argv)
         if (o.devices.empty()) throw Error("--devices needs a comma-separated list of GPU ids");
     } else if (m.count("device")) o.devices.push_back(o.device);
     o.chunk_reads = std::stoull(opt(m, "chunk-reads", "16384"));
+    o.keep_text = o.write_console || o.also_validate;
     MapOutput out = map_reads_multi(ix, reads, o, prefix);
     fprintf(stderr, "[vgaligner] %llu GPU context(s), %llu batch(es)\n", (unsigned long long)out.n_devices, (unsigned long long)out.n_chunks);
     fprintf(stderr, "[vgaligner] Chaining took: %.0f ms\n", out.ms_map);

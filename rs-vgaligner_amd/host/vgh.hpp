@@ -118,6 +118,9 @@ struct MapOptions {
     // chunks of at most `chunk_reads` reads (0 = the whole slice at once) so that host and device memory stay bounded.
     std::vector<int> devices;
     uint64_t chunk_reads = 16384;
+    // false: map_reads_multi writes the GAF files chunk by chunk and returns no text (the CLI without -C / -v); true: the
+    // whole GAF text comes back in MapOutput
+    bool keep_text = true;
     bool also_validate = false;          // -v: write validation records (src/validate.rs:18-102, map.rs:186-208)
     std::string validation_path;         // -P
 };

@@ -12,6 +12,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 namespace vgh {
@@ -179,6 +182,33 @@ std::vector<Shard> plan_shards(const std::vector<uint64_t> &len, uint32_t n_slot
 
 namespace {
 
+// GAF text of reads [0, n) built by several threads over contiguous ranges (the order of the reads is kept)
+template <typename F>
+std::string text_of_reads(uint64_t n, unsigned n_threads, F per_read)
+{
+    const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_threads, n / 64 + 1));
+    std::vector<std::string> parts(T);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&, t]() {
+            const uint64_t a = n * t / T, b = n * (t + 1) / T;
+            for (uint64_t r = a; r < b; r++) per_read(r, parts[t]);
+        });
+    for (auto &x : th) x.join();
+    size_t tot = 0;
+    for (auto &q : parts) tot += q.size();
+    std::string out;
+    out.reserve(tot);
+    for (auto &q : parts) out += q;
+    return out;
+}
+
+unsigned text_threads()
+{
+    if (const char *e = getenv("VGA_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
+    return std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+}
+
 struct ChunkOut {
     std::string chains, aligns;
     uint64_t n_aligned = 0, n_anchors = 0, poa_cells = 0;
@@ -190,6 +220,15 @@ ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequenc
 {
     ChunkOut out;
     const uint64_t n = e0 - b0;
+    const bool trace = getenv("VGA_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!trace) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[vgh-trace] reads [%llu, %llu): %-28s %9.3f ms\n", (unsigned long long)b0, (unsigned long long)e0, what,
+                std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     std::string concat;
     std::vector<uint64_t> off(n + 1, 0);
     uint64_t tot = 0;
@@ -208,26 +247,39 @@ ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequenc
     if (vga_map_batch(b, &mp, &m) != VGA_OK) { const std::string e = vga_last_error(ctx); vga_batch_destroy(b); throw Error(e); }
     out.n_anchors = m->n_anchors;
     out.ms_map = m->ms_total;
-    // chains GAF (map.rs:123-145): every chain of every read, in order
-    for (uint64_t r = 0; r < n; r++)
-        for (uint64_t c = m->chain_off[r]; c < m->chain_off[r + 1]; c++) out.chains += gaf_from_chain(ix, inputs[b0 + r], m, r, c);
+    mark("batch + vga_map_batch");
+    // chains GAF (map.rs:123-145): every chain of every read, in order.  Text generation is host work that only reads the
+    // chains: it runs beside the alignment call, which keeps the GPU busy
+    const unsigned T = text_threads();
+    std::string chain_err;
+    std::thread chains_thread([&]() {
+        try {
+            out.chains = text_of_reads(n, opt.also_align ? std::max(1u, T / 2) : T, [&](uint64_t r, std::string &dst) {
+                for (uint64_t c = m->chain_off[r]; c < m->chain_off[r + 1]; c++) dst += gaf_from_chain(ix, inputs[b0 + r], m, r, c);
+            });
+        } catch (const std::exception &e) { chain_err = e.what(); }
+    });
     if (opt.also_align) {
         vga_poa_params pp;
         vga_poa_default_params(&pp);
         vga_align_result *a = nullptr;
         if (vga_align_batch(b, m, (uint32_t)opt.align_best_n, &pp, &a) != VGA_OK) {
             const std::string e = vga_last_error(ctx);
+            chains_thread.join();
             vga_map_result_free(m); vga_batch_destroy(b);
             throw Error(e);
         }
         out.ms_align = a->ms_total;
         out.poa_cells = a->poa_cells;
-        for (uint64_t r = 0; r < n; r++) {
-            out.aligns += gaf_from_alignment(inputs[b0 + r], a, r);
-            out.n_aligned += a->aligned[r];
-        }
+        mark("vga_align_batch");
+        out.aligns = text_of_reads(n, std::max(1u, T / 2), [&](uint64_t r, std::string &dst) { dst += gaf_from_alignment(inputs[b0 + r], a, r); });
+        for (uint64_t r = 0; r < n; r++) out.n_aligned += a->aligned[r];
         vga_align_result_free(a);
+        mark("alignments GAF text");
     }
+    chains_thread.join();
+    mark("chains GAF text (joined)");
+    if (!chain_err.empty()) { vga_map_result_free(m); vga_batch_destroy(b); throw Error(chain_err); }
     vga_map_result_free(m);
     vga_batch_destroy(b);
     return out;
@@ -322,30 +374,80 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
     const std::vector<Shard> plan = plan_shards(len, n_slots, opt.chunk_reads);
     std::vector<ChunkOut> parts(plan.size());
     std::vector<std::string> errors(n_slots);
+    // Streaming output: when the caller does not need the GAF text back (the CLI without -C / -v), a writer thread appends
+    // every finished chunk to the files in read order and drops its text, so that host memory holds a few chunks, not the
+    // run.  (A prefix ending in .gaf makes the alignments overwrite the chains file, map.rs:174-178: that quirk is kept
+    // by the non-streaming path.)
+    const bool same_file = out_prefix.size() >= 4 && out_prefix.compare(out_prefix.size() - 4, 4, ".gaf") == 0;
+    const bool stream = !opt.keep_text && !out_prefix.empty() && !same_file && !opt.also_validate;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<uint8_t> done(plan.size(), 0);
+    bool abort_writer = false;
+    std::string writer_err;
+    std::thread writer;
+    if (stream)
+        writer = std::thread([&]() {
+            try {
+                std::ofstream fc(out_prefix + "-chains.gaf", std::ios::binary), fa;
+                if (!fc) throw Error("Couldn't create file " + out_prefix + "-chains.gaf");
+                if (opt.also_align) {
+                    fa.open(out_prefix + "-alignments.gaf", std::ios::binary);
+                    if (!fa) throw Error("Couldn't create file " + out_prefix + "-alignments.gaf");
+                }
+                for (size_t i = 0; i < plan.size(); i++) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&]() { return done[i] || abort_writer; });
+                        if (!done[i]) return;
+                    }
+                    fc.write(parts[i].chains.data(), (std::streamsize)parts[i].chains.size());
+                    if (opt.also_align) fa.write(parts[i].aligns.data(), (std::streamsize)parts[i].aligns.size());
+                    if (!fc || (opt.also_align && !fa)) throw Error("Couldn't write the GAF files under " + out_prefix);
+                    std::string().swap(parts[i].chains);
+                    std::string().swap(parts[i].aligns);
+                }
+            } catch (const std::exception &e) { writer_err = e.what(); }
+        });
     std::vector<std::thread> workers;
     for (uint32_t slot = 0; slot < n_slots; slot++)
         workers.emplace_back([&, slot]() {
             try {
                 for (size_t i = 0; i < plan.size(); i++)
-                    if (plan[i].slot == slot) parts[i] = map_chunk(ctxs[slot], ix, inputs, plan[i].begin, plan[i].end, opt);
-            } catch (const std::exception &e) { errors[slot] = e.what(); }
+                    if (plan[i].slot == slot) {
+                        parts[i] = map_chunk(ctxs[slot], ix, inputs, plan[i].begin, plan[i].end, opt);
+                        { std::lock_guard<std::mutex> lk(mu); done[i] = 1; }
+                        cv.notify_all();
+                    }
+            } catch (const std::exception &e) {
+                errors[slot] = e.what();
+                { std::lock_guard<std::mutex> lk(mu); abort_writer = true; }
+                cv.notify_all();
+            }
         });
     for (std::thread &t : workers) t.join();
+    if (writer.joinable()) writer.join();
     release();
     for (const std::string &e : errors)
         if (!e.empty()) throw Error(e);
+    if (!writer_err.empty()) throw Error(writer_err);
     MapOutput out;
     out.n_reads = inputs.size();
     out.n_devices = n_slots;
     out.n_chunks = plan.size();
     std::vector<double> ms_map(n_slots, 0.0), ms_align(n_slots, 0.0);
     for (size_t i = 0; i < plan.size(); i++) {  // read order
-        out.chains_gaf += parts[i].chains;
-        out.alignments_gaf += parts[i].aligns;
+        if (!stream) {
+            out.chains_gaf += parts[i].chains;
+            out.alignments_gaf += parts[i].aligns;
+            std::string().swap(parts[i].chains);
+            std::string().swap(parts[i].aligns);
+        }
         out.n_aligned += parts[i].n_aligned; out.n_anchors += parts[i].n_anchors; out.poa_cells += parts[i].poa_cells;
         ms_map[plan[i].slot] += parts[i].ms_map; ms_align[plan[i].slot] += parts[i].ms_align;
     }
     for (uint32_t s = 0; s < n_slots; s++) { out.ms_map = std::max(out.ms_map, ms_map[s]); out.ms_align = std::max(out.ms_align, ms_align[s]); }
+    if (stream) return out;
     finish(out, ix, inputs, opt, out_prefix);
     return out;
 }
