@@ -3016,7 +3016,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             {
                 double lsum = 0, nsum = 0;
                 uint32_t lmax = 0;
-                for (uint64_t i = cur.i0; i < cur.i1; i++) { lsum += G[order[i]].life; nsum += (double)G[order[i]].ntab.size(); lmax = std::max(lmax, G[order[i]].life); }
+                for (uint64_t i = cur.i0; i < cur.i1; i++) { lsum += G[order[i]].life; nsum += (double)G[order[i]].n_ntab; lmax = std::max(lmax, G[order[i]].life); }
                 double csum = 0, vsum = 0, rsum = 0, esum = 0;
                 for (uint64_t i = cur.i0; i < cur.i1; i++) {
                     csum += (double)S.h_outs.p[i - cur.i0].cells; vsum += (double)S.h_outs.p[i - cur.i0].vcells; rsum += G[order[i]].N;
