@@ -145,6 +145,33 @@ def test_config3_full_length_alignments_are_self_consistent(env):
     assert al2.cigar == al.cigar and al2.cs == al.cs and np.array_equal(al2.path_handles, al.path_handles)
 
 
+def test_config3_whole_bench_batch(env):
+    """BASELINE config #3 at the size the bench line is quoted on: 10 000 x 10 kbp reads in one batch.  Every read aligns;
+    every CIGAR consumes its read and spans its path; 400 alignments spread over the batch are replayed base by base; and
+    the records of the first 192 reads equal those of the 192-read batch (a read's result does not depend on the batch
+    it travels in, whichever sub-batch, launch and arena it lands in)."""
+    p, hi, ctx, arr = env
+    reads = p.readsim.config3_reads(DRB1, 10000)
+    seqs = [r.seq for r in reads]
+    b = ctx.batch(seqs)
+    al = b.align(b.map())
+    assert int(al.aligned.sum()) == 10000
+    for r in range(10000):
+        runs = re.findall(r"(\d+)([MID])", al.cigar[r])
+        nM = sum(int(n) for n, op in runs if op == "M")
+        nI = sum(int(n) for n, op in runs if op == "I")
+        nD = sum(int(n) for n, op in runs if op == "D")
+        assert nM + nI == len(seqs[r]) and nM + nD == int(al.path_length[r]) and nM == int(al.block_length[r]), f"read {r}"
+    edges_of = _edges_of(arr)
+    for r in list(range(0, 10000, 27)) + list(range(9970, 10000)):
+        _check_alignment(seqs[r], al, r, arr, edges_of)
+    small = ctx.batch(seqs[:192])
+    al_s = small.align(small.map())
+    assert al_s.cigar == al.cigar[:192] and al_s.cs == al.cs[:192]
+    assert np.array_equal(al_s.path_handles, al.path_handles[:int(al.path_off[192])])
+    assert np.array_equal(al_s.best_score, al.best_score[:192])
+
+
 def _run_and_replay(gfa, n_reads, min_aligned):
     p = pkg()
     hi = p.HostIndex.build_from_gfa(gfa, 11)

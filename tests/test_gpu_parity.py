@@ -247,7 +247,7 @@ def test_subgraphs_from_host_threads_match_the_device_kernels(oracle, ctx, drb1,
     assert dev.cigar == host.cigar and dev.path_handles.tolist() == host.path_handles.tolist() and dev.poa_cells == host.poa_cells
     ix4 = oracle.Index(oracle.Graph.from_gfa(config4_gfa), 11)
     upload_oracle_index(ctx, ix4)
-    reads4 = pkg().readsim.config3_reads(config4_gfa, 12)
+    reads4 = pkg().readsim.config3_reads(config4_gfa, 28)
     host4 = _check_align(oracle, ctx, ix4, reads4)
     monkeypatch.delenv("VGA_SUBGRAPH")
     dev4 = _check_align(oracle, ctx, ix4, reads4)
