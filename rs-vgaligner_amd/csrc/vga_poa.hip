@@ -2461,7 +2461,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         if (W.pool_size < want) {
             size_t free_b = 0, total_b = 0;
             POA_CHECK(hipMemGetInfo(&free_b, &total_b));
-            const uint64_t avail = (uint64_t)((double)(free_b + W.pool_size) * 0.85);
+            // leave room for everything else this context allocates (staging of three sub-batches, the subgraph store, the
+            // map workspace): 15 % of what is free, at least 16 GB -- two processes sharing a GPU otherwise starve each other
+            const uint64_t have = free_b + W.pool_size;
+            const uint64_t reserve = std::max<uint64_t>((uint64_t)((double)have * 0.15), 16ull << 30);
+            const uint64_t avail = have > reserve ? have - reserve : have / 4;
             const uint64_t target = std::min(std::max<uint64_t>(2 * want, 8ull << 30), avail) & ~(POA_CHUNK - 1);
             if (target > W.pool_size) {
                 if (W.pool) { (void)hipFree(W.pool); W.pool = nullptr; W.pool_size = 0; }
