@@ -96,7 +96,10 @@ typedef struct {
     uint32_t bandwidth;           /* 50   (src/subcommands/map_main.rs:103) */
     uint64_t max_gap;             /* 1000 (map_main.rs:30-34) */
     uint32_t chain_min_n_anchors; /* 3    (map_main.rs:42-46) */
-    int only_forward;             /* 1    (src/map.rs:62); 0 is not supported yet */
+    int only_forward;             /* 1    (src/map.rs:62).  0 = anchors_for_query(.., false) (src/chain.rs:154-155): every
+                                   * k-mer record becomes an anchor and bit 31 of target_begin / target_end is the
+                                   * orientation of that end (1 = reverse strand); k <= 13; such chains cannot be passed
+                                   * to vga_align_batch unless they are all-forward */
     int emit_dp;                  /* 1: the result also carries Anchor.id, f(i) and the best predecessor of every anchor
                                    *    (what the reference keeps inside chain_anchors; parity checks read them).
                                    * 0: anchor_id / max_chain_score / best_pred_id are NULL -- the GAF writers and

@@ -288,6 +288,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     std::vector<double> proxy(n, 0.0);
     std::vector<sg_desc> descs(on_device ? n : 0);
     std::vector<uint64_t> q_src(on_device ? n : 0);
+    std::atomic<int> has_reverse{0};
     vga_parallel_for(n, [&](uint64_t p) {
         const uint64_t r = prob_read[p], c = prob_chain[p];
         const uint64_t a0 = m->anchor_off[r];
@@ -296,6 +297,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
             const uint64_t ai = a0 + m->chain_anchor_idx[t];
             lo = std::min(lo, m->target_begin[ai]);
             hi = std::max(hi, m->target_end[ai]);
+            if ((m->target_begin[ai] | m->target_end[ai]) >> 31) has_reverse = 1;  // (vga_map_params.only_forward = 0)
             // smallest / largest position over the anchors' begins and inclusive ends (align.rs:286-308; chain.rs:65-70)
             const uint32_t s = m->target_begin[ai], e = m->target_end[ai] - 1;
             pmin = std::min(pmin, std::min(s, e));
@@ -318,6 +320,9 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
             q_src[p] = b->read_off[r];
         }
     });
+    if (has_reverse)
+        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED,
+                             "a chain to be aligned holds reverse-strand anchors: RangeOrient::Reverse / Both (src/align.rs:365-387) is not supported");
     feed.proxy = proxy.data();
     double sub_ms = 0;
     const unsigned n_thr = std::max(1u, vga_host_threads(n));

@@ -29,6 +29,9 @@ struct vga_dev_index {
     uint64_t table_entries = 0;
     uint2 *d_pos = nullptr;
     uint64_t n_pos_words = 0;
+    // the same with the records of every orientation (k <= 13): bit 31 of target_begin / target_end = reverse strand
+    uint32_t *d_table_all = nullptr;
+    uint2 *d_pos_all = nullptr;
     // the graph itself for the device-side subgraph extraction (vga_subgraph.hip): forward sequence, node starts
     // (n_nodes + 1), per node the first edge / the number of incoming edges, the edge lists as packed handles
     char *d_seq_fwd = nullptr;

@@ -74,6 +74,8 @@ static void vga_index_release(vga_dev_index &ix)
 {
     if (ix.d_table) (void)hipFree(ix.d_table);
     if (ix.d_pos) (void)hipFree(ix.d_pos);
+    if (ix.d_table_all) (void)hipFree(ix.d_table_all);
+    if (ix.d_pos_all) (void)hipFree(ix.d_pos_all);
     if (ix.d_seq_fwd) (void)hipFree(ix.d_seq_fwd);
     if (ix.d_node_start) (void)hipFree(ix.d_node_start);
     if (ix.d_edge_idx) (void)hipFree(ix.d_edge_idx);
@@ -251,57 +253,74 @@ static int vga_index_upload_impl(vga_ctx *ctx, const vga_index_desc *d)
     ix.edges.resize(d->n_edges);
     for (uint64_t i = 0; i < d->n_edges; i++) ix.edges[i] = (uint32_t)d->edges[i];
 
-    // Build the probe table on the host, then copy once.
+    // Build the probe tables on the host, then copy once: the forward/forward records only (what map_reads asks for,
+    // src/map.rs:62) and, for k <= 13, every record with the orientations of its two ends in bit 31 of the positions
+    // (anchors_for_query(..., only_forward = false), src/chain.rs:154-155).
     const uint32_t k = d->kmer_length;
     const uint64_t entries = 1ull << (2 * k);
-    std::vector<uint32_t> table(entries, 0xFFFFFFFFu);
-    std::vector<uint2> pos;
-    pos.reserve(d->n_kmer_pos + d->n_kmers);
-    for (uint64_t g = 0; g < d->n_kmers; g++) {
-        const char *key = d->kmer_keys + g * k;
-        uint64_t packed = 0;
-        bool acgt = true;
-        for (uint32_t t = 0; t < k; t++) {
-            int c = vga_base_code(key[t]);
-            if (c < 0) { acgt = false; break; }
-            packed = (packed << 2) | (uint64_t)c;
-        }
-        if (!acgt) {
-            vga_index_release(ctx->index);
-            return vga_set_error(ctx, VGA_ERR_UNSUPPORTED,
-                                 "k-mer %llu of the index holds a base outside upper-case A/C/G/T; the 2-bit probe "
-                                 "table cannot represent it",
-                                 (unsigned long long)g);
-        }
-        uint64_t s = d->kmer_starts[g];
-        if (s >= d->n_kmer_pos) { vga_index_release(ctx->index); return vga_set_error(ctx, VGA_ERR_ARG, "kmer_starts out of range"); }
-        size_t header = pos.size();
-        pos.push_back(make_uint2(0u, 0u));
-        uint32_t cnt = 0;
-        for (uint64_t e = s; e < d->n_kmer_pos; e++) {
-            const vga_kmerpos &p = d->kmer_pos_table[e];
-            if (p.start_orient == 1 && p.end_orient == 1 && p.start == UINT64_MAX && p.end == UINT64_MAX) break;
-            // src/chain.rs:154: only forward/forward records become anchors (map.rs:62)
-            if (p.start_orient == 0 && p.end_orient == 0) {
-                pos.push_back(make_uint2((uint32_t)p.start, (uint32_t)p.end));
-                cnt++;
+    auto build = [&](bool all, std::vector<uint32_t> &table, std::vector<uint2> &pos) -> int {
+        table.assign(entries, 0xFFFFFFFFu);
+        pos.clear();
+        pos.reserve(d->n_kmer_pos + d->n_kmers);
+        for (uint64_t g = 0; g < d->n_kmers; g++) {
+            const char *key = d->kmer_keys + g * k;
+            uint64_t packed = 0;
+            bool acgt = true;
+            for (uint32_t t = 0; t < k; t++) {
+                int c = vga_base_code(key[t]);
+                if (c < 0) { acgt = false; break; }
+                packed = (packed << 2) | (uint64_t)c;
             }
+            if (!acgt)
+                return vga_set_error(ctx, VGA_ERR_UNSUPPORTED,
+                                     "k-mer %llu of the index holds a base outside upper-case A/C/G/T; the 2-bit probe "
+                                     "table cannot represent it",
+                                     (unsigned long long)g);
+            uint64_t s = d->kmer_starts[g];
+            if (s >= d->n_kmer_pos) return vga_set_error(ctx, VGA_ERR_ARG, "kmer_starts out of range");
+            size_t header = pos.size();
+            pos.push_back(make_uint2(0u, 0u));
+            uint32_t cnt = 0;
+            for (uint64_t e = s; e < d->n_kmer_pos; e++) {
+                const vga_kmerpos &p = d->kmer_pos_table[e];
+                if (p.start_orient == 1 && p.end_orient == 1 && p.start == UINT64_MAX && p.end == UINT64_MAX) break;
+                if (all) {
+                    pos.push_back(make_uint2((uint32_t)p.start | (p.start_orient ? 0x80000000u : 0u), (uint32_t)p.end | (p.end_orient ? 0x80000000u : 0u)));
+                    cnt++;
+                } else if (p.start_orient == 0 && p.end_orient == 0) {  // src/chain.rs:154
+                    pos.push_back(make_uint2((uint32_t)p.start, (uint32_t)p.end));
+                    cnt++;
+                }
+            }
+            if (cnt == 0) {
+                pos.pop_back();  // k-mer only on the reverse strand: a forward-only probe misses
+                continue;
+            }
+            pos[header].x = cnt;
+            if (pos.size() >= 0xFFFFFFFFull) return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "position table too large");
+            table[packed] = (uint32_t)header;
         }
-        if (cnt == 0) {
-            pos.pop_back();  // k-mer only on the reverse strand: a forward-only probe misses
-            continue;
-        }
-        pos[header].x = cnt;
-        if (pos.size() >= 0xFFFFFFFFull) { vga_index_release(ctx->index); return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "position table too large"); }
-        table[packed] = (uint32_t)header;
-    }
-    if (pos.empty()) pos.push_back(make_uint2(0u, 0u));
+        if (pos.empty()) pos.push_back(make_uint2(0u, 0u));
+        return VGA_OK;
+    };
+    std::vector<uint32_t> table;
+    std::vector<uint2> pos;
+    if (int rc = build(false, table, pos)) { vga_index_release(ctx->index); return rc; }
     ix.table_entries = entries;
     ix.n_pos_words = pos.size();
     VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_table, entries * sizeof(uint32_t)));
     VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_pos, pos.size() * sizeof(uint2)));
     VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_table, table.data(), entries * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_pos, pos.data(), pos.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    VGA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (k <= 13) {
+        if (int rc = build(true, table, pos)) { vga_index_release(ctx->index); return rc; }
+        VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_table_all, entries * sizeof(uint32_t)));
+        VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_pos_all, pos.size() * sizeof(uint2)));
+        VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_table_all, table.data(), entries * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        VGA_HIP_CHECK(ctx, hipMemcpyAsync(ix.d_pos_all, pos.data(), pos.size() * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+        VGA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     // the graph for the device-side subgraph extraction
     const size_t nn1 = (size_t)d->n_nodes + 1;
     VGA_HIP_CHECK(ctx, hipMalloc((void **)&ix.d_seq_fwd, d->seq_length + 16));

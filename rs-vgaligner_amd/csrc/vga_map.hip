@@ -189,6 +189,13 @@ __global__ __launch_bounds__(VGA_SORT_NT) void k_anchor_sort(const uint64_t *__r
     }
 }
 
+// sort keys of the both-orientations order: reverse-strand ends (bit 31 set) come first
+__global__ __launch_bounds__(256) void k_flip_orient_bit(uint32_t *key, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) key[i] ^= 0x80000000u;
+}
+
 // one block per read: gather sorted fields (perm holds read-local anchor ids)
 __global__ __launch_bounds__(256) void k_anchor_gather_seg(const uint64_t *__restrict__ anchor_off,
                                                            const uint32_t *__restrict__ perm,
@@ -247,8 +254,8 @@ __global__ __launch_bounds__(VGA_WAVE) void k_chain(
         if (i > 0) {
             const int min_j = (bandwidth > i) ? 0 : (int)(i - bandwidth);  // src/chain.rs:404-407
             if (j_l >= min_j) {
-                // score_anchor(a = j_l, b = i), src/chain.rs:274-368, all orientations Forward
-                if (!(qb_l >= qbi || te_l >= tei)) {
+                // score_anchor(a = j_l, b = i), src/chain.rs:274-368; bit 31 = orientation, see k_chain4
+                if ((tb_l >> 31) == (tei >> 31) && (te_l >> 31) == (tei >> 31) && (tbi >> 31) == (tei >> 31) && !(qb_l >= qbi || te_l >= tei)) {
                     const uint64_t ql = (uint64_t)(qbi - qb_l);
                     const uint64_t tbd = tbi > tb_l ? (uint64_t)(tbi - tb_l) : (uint64_t)(tb_l - tbi);
                     const uint64_t ted = (uint64_t)(tei - te_l);
@@ -400,8 +407,11 @@ __global__ __launch_bounds__(256) void k_chain4(
                 const int min_j = (bandwidth > i) ? 0 : (int)(i - bandwidth);  // src/chain.rs:404-407
                 bool ok = false;
                 if (j_l >= min_j) {
-                    // score_anchor(a = j_l, b = i), src/chain.rs:274-368, all orientations Forward
-                    if (!(qb_l >= qbi || te_l >= tei)) {
+                    // score_anchor(a = j_l, b = i), src/chain.rs:274-368.  Bit 31 of a target coordinate is its orientation
+                    // (always 0 with only_forward): the four ends must agree (chain.rs:280-283), then positions compare
+                    const uint32_t ob = tei >> 31;
+                    const bool same = (tb_l >> 31) == ob && (te_l >> 31) == ob && (tbi >> 31) == ob;
+                    if (same && !(qb_l >= qbi || te_l >= tei)) {
                         const uint64_t ql = (uint64_t)(qbi - qb_l);
                         const uint64_t tbd = tbi > tb_l ? (uint64_t)(tbi - tb_l) : (uint64_t)(tb_l - tbi);
                         const uint64_t ted = (uint64_t)(tei - te_l);
@@ -563,8 +573,11 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
     *out = nullptr;
     (void)hipSetDevice(ctx->device);
     if (!ctx->index.loaded) return vga_set_error(ctx, VGA_ERR_NO_INDEX, "vga_map_batch: no index uploaded");
-    if (!params->only_forward)
-        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "only_forward=0 (reverse-strand anchors) is not supported yet");
+    // only_forward = 0 (anchors_for_query(..., false), src/chain.rs:154-155): every k-mer record becomes an anchor; the
+    // orientation of each end travels in bit 31 of target_begin / target_end.  vga_align_batch accepts forward chains only.
+    const bool all_orients = !params->only_forward;
+    if (all_orients && !ctx->index.d_table_all)
+        return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "only_forward=0 needs the all-orientation probe table, which is built for k <= 13");
     if (params->bandwidth == 0 || params->bandwidth > 64)
         return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "bandwidth %u: the wavefront chaining kernel supports 1..64", params->bandwidth);
     if (params->max_gap > (1u << 22))
@@ -615,8 +628,10 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
     MAP_CHECK(ws.anchor_off.reserve(R + 1));
     int t_total = vga_timer_begin(ctx, "map_total", 0);
     int t1 = vga_timer_begin(ctx, "kmer_probe_count", 0);
+    const uint32_t *probe_table = all_orients ? ix.d_table_all : ix.d_table;
+    const uint2 *probe_pos = all_orients ? ix.d_pos_all : ix.d_pos;
     hipLaunchKernelGGL(k_kmer_probe<false>, dim3((unsigned)R), dim3(VGA_PROBE_NT), 0, st, b->d_reads, b->d_read_off, ix.k,
-                       ix.d_table, ix.d_pos, ws.cnt.p, (const uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                       probe_table, probe_pos, ws.cnt.p, (const uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                        (uint32_t *)nullptr, (uint32_t *)nullptr);
     vga_timer_end(ctx, t1);
     MAP_CHECK(ws.h_cnt.reserve(R));
@@ -661,17 +676,20 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
     }
     int t2 = vga_timer_begin(ctx, "kmer_probe_emit", b->total_bases + 4 * nkm + 8 * total + 16 * total);
     hipLaunchKernelGGL(k_kmer_probe<true>, dim3((unsigned)R), dim3(VGA_PROBE_NT), 0, st, b->d_reads, b->d_read_off, ix.k,
-                       ix.d_table, ix.d_pos, (uint32_t *)nullptr, ws.anchor_off.p, ws.a_qb.p, ws.a_tb.p, ws.a_te.p, ws.a_idx.p);
+                       probe_table, probe_pos, (uint32_t *)nullptr, ws.anchor_off.p, ws.a_qb.p, ws.a_tb.p, ws.a_te.p, ws.a_idx.p);
     vga_timer_end(ctx, t2);
 
     // ---- K2: sort by target_end
     uint32_t nbits = 1;
     while ((1ull << nbits) <= ix.seq_length && nbits < 32) nbits++;
-    const uint32_t n_pass = (nbits + 7) / 8;
+    // with both orientations the order is (orientation descending, position ascending), src/chain.rs:386-389: the key is
+    // the end position with its orientation bit flipped, all 32 bits sorted
+    const uint32_t n_pass = all_orients ? 4 : (nbits + 7) / 8;
     // the keys are sorted in place of a_te (ping) / key_b (pong); the original te is re-gathered from a copy
     vga_dbuf<uint32_t> &key_a = ws.key_a;
     MAP_CHECK(key_a.reserve(An));
     if (An) MAP_CHECK(hipMemcpyAsync(key_a.p, ws.a_te.p, An * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    if (An && all_orients) hipLaunchKernelGGL(k_flip_orient_bit, dim3((unsigned)((An + 255) / 256)), dim3(256), 0, st, key_a.p, (uint64_t)An);
     int t3 = vga_timer_begin(ctx, "anchor_sort", (uint64_t)n_pass * 16 * total + 24 * total);
     hipLaunchKernelGGL(k_anchor_sort, dim3((unsigned)R), dim3(VGA_SORT_NT), 0, st, ws.anchor_off.p, n_pass, key_a.p,
                        ws.a_idx.p, ws.key_b.p, ws.val_b.p);

@@ -43,17 +43,18 @@ def upload_oracle_index(ctx, ix):
     ctx.upload_index(**oracle_index_arrays(ix))
 
 
-def compare_map(o, ix, mo, seqs, bandwidth=50, max_gap=1000, min_anchors=3):
-    """GPU vga_map_batch output vs the oracle, read by read, bit for bit."""
+def compare_map(o, ix, mo, seqs, bandwidth=50, max_gap=1000, min_anchors=3, only_forward=True):
+    """GPU vga_map_batch output vs the oracle, read by read, bit for bit.  With only_forward=False the GPU carries the
+    orientation of a target coordinate in its bit 31 (include/vga_hip.h)."""
     for r, s in enumerate(seqs):
-        ref = o.chain_anchors(ix, s, bandwidth, max_gap, min_anchors)
+        ref = o.chain_anchors(ix, s, bandwidth, max_gap, min_anchors, only_forward=only_forward)
         a0, a1 = int(mo.anchor_off[r]), int(mo.anchor_off[r + 1])
         sa = ref.sorted_anchors
         assert a1 - a0 == len(sa), f"read {r}: {a1 - a0} anchors on the GPU, {len(sa)} in the oracle"
         assert mo.anchor_id[a0:a1].tolist() == [x.id for x in sa], f"read {r}: sorted anchor ids differ"
         assert mo.query_begin[a0:a1].tolist() == [x.query_begin for x in sa]
-        assert mo.target_begin[a0:a1].tolist() == [x.target_begin[1] for x in sa]
-        assert mo.target_end[a0:a1].tolist() == [x.target_end[1] for x in sa]
+        assert mo.target_begin[a0:a1].tolist() == [x.target_begin[1] | (x.target_begin[0] << 31) for x in sa]
+        assert mo.target_end[a0:a1].tolist() == [x.target_end[1] | (x.target_end[0] << 31) for x in sa]
         gf = mo.max_chain_score[a0:a1]
         of = np.array([x.max_chain_score for x in sa], dtype=np.float64)
         assert gf.view(np.uint64).tolist() == of.view(np.uint64).tolist(), f"read {r}: f(i) bit patterns differ"

@@ -56,6 +56,71 @@ def test_anchor_vectors_of_the_reference(oracle, ctx):
     compare_map(oracle, ix2, mo2, ["AAAAACTTTTTT"])
 
 
+def test_reverse_strand_anchor_vectors_of_the_reference(oracle, ctx, drb1):
+    """vga_map_params.only_forward = 0, i.e. anchors_for_query(.., false): the reference's own vectors for it
+    (src/chain.rs:806-976: test_simple_anchors, test_simple_anchors_reverse, _reverse_2, test_anchors, test_no_anchors(_2),
+    test_chains, test_chains_2) through the device probe / sort / chaining, and GPU == oracle on real reads.  Bit 31 of a
+    target coordinate is its orientation.  vga_align_batch refuses chains that hold reverse-strand anchors."""
+    p = pkg()
+    mp = p.default_map_params()
+    mp.only_forward = 0
+    mp.chain_min_n_anchors = 1
+    REV = 1 << 31
+    # test_simple_anchors
+    ix = oracle.Index(oracle.Graph.from_nodes_edges([(1, "ACT")], []), 3)
+    upload_oracle_index(ctx, ix)
+    mo = ctx.batch(["ACT"]).map(mp)
+    assert int(mo.n_anchors) == 1
+    assert (int(mo.query_begin[0]), int(mo.target_begin[0]), int(mo.target_end[0])) == (0, 0, 3)
+    # test_simple_anchors_reverse / _reverse_2: AAA - (CCC | GGG) - AAA, reads from the reverse strand
+    diamond = oracle.Graph.from_nodes_edges([(1, "AAA"), (2, "CCC"), (3, "GGG"), (4, "AAA")], [(1, 2), (1, 3), (2, 4), (3, 4)])
+    ix = oracle.Index(diamond, 3)
+    upload_oracle_index(ctx, ix)
+    mo = ctx.batch(["TTT"]).map(mp)
+    assert int(mo.n_anchors) == 2 and all(int(x) & REV for x in mo.target_begin) and all(int(x) & REV for x in mo.target_end)
+    by_id = sorted(zip(mo.anchor_id.tolist(), mo.target_begin.tolist(), mo.target_end.tolist()))
+    nodes = [(ix.handle_from_seqpos(1, tb & ~REV), ix.handle_from_seqpos(1, (te & ~REV) - 1)) for _, tb, te in by_id]
+    assert nodes == [(4 * 2 + 1, 4 * 2 + 1), (1 * 2 + 1, 1 * 2 + 1)]  # anchor 0 on node 4 reversed, anchor 1 on node 1 reversed
+    compare_map(oracle, ix, mo, ["TTT"], min_anchors=1, only_forward=False)
+    ix9 = oracle.Index(diamond, 9)
+    upload_oracle_index(ctx, ix9)
+    mo = ctx.batch(["TTTCCCTTT"]).map(mp)
+    assert int(mo.n_anchors) == 1
+    assert ix9.handle_from_seqpos(1, int(mo.target_begin[0]) & ~REV) == 4 * 2 + 1
+    assert ix9.handle_from_seqpos(1, (int(mo.target_end[0]) & ~REV) - 1) == 1 * 2 + 1
+    # test_anchors / test_no_anchors / test_no_anchors_2 / test_chains
+    ix = oracle.Index(simple_graph(oracle), 3)
+    upload_oracle_index(ctx, ix)
+    seqs = ["ACTGCA", "AAATTT", "", "TGCAGT"]
+    mo = ctx.batch(seqs).map(mp)
+    counts = np.diff(mo.anchor_off).tolist()
+    assert counts[0] >= 4 and counts[1] == 0 and counts[2] == 0
+    compare_map(oracle, ix, mo, seqs, min_anchors=1, only_forward=False)
+    assert not mo.chains_of(0)[0][0]
+    # test_chains_2: the whole linearisation of test.gfa as a read, min 2 anchors
+    g = oracle.Graph.from_gfa(os.path.join(DATA, "test.gfa"))
+    ixt = oracle.Index(g, 11)
+    upload_oracle_index(ctx, ixt)
+    mp.chain_min_n_anchors = 2
+    mo = ctx.batch([ixt.seq_fwd]).map(mp)
+    assert int(mo.n_anchors) > 0 and not mo.chains_of(0)[0][0]
+    compare_map(oracle, ixt, mo, [ixt.seq_fwd], min_anchors=2, only_forward=False)
+    # real reads, both strands: forward reads and their reverse complements against DRB1-3123
+    _, ixd = drb1
+    upload_oracle_index(ctx, ixd)
+    mp.chain_min_n_anchors = 3
+    reads = p.readsim.config2_reads(DRB1, 12) + p.readsim.simulate_reads(DRB1, 3, 1200, 0.03, 0.03, 0.04, seed=21)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    seqs = [r.seq for r in reads] + ["".join(comp[c] for c in reversed(r.seq)) for r in reads[:8]]
+    b = ctx.batch(seqs)
+    mo = b.map(mp)
+    compare_map(oracle, ixd, mo, seqs, only_forward=False)
+    assert any(int(x) & REV for x in mo.target_end)
+    with pytest.raises(p.VgaError) as e:  # RangeOrient::Reverse / Both is not built
+        b.align(mo)
+    assert e.value.code == -4
+
+
 def test_map_config1_placeholder(oracle, ctx):
     """BASELINE config #1: test.gfa + single-read-test.fa, k=11 -> one placeholder chain"""
     g = oracle.Graph.from_gfa(os.path.join(DATA, "test.gfa"))
@@ -323,10 +388,6 @@ def test_unsupported_inputs_fail_loudly(oracle, ctx, drb1):
     with pytest.raises(p.VgaError) as e:
         ctx.batch(["ACGT" * 10]).map(mp)
     assert e.value.code == -4
-    mp = p.default_map_params()
-    mp.only_forward = 0
-    with pytest.raises(p.VgaError):
-        ctx.batch(["ACGT" * 10]).map(mp)
     with pytest.raises(p.VgaError):  # edge with src >= dst
         ctx.poa_batch([(["AC", "GT"], [(1, 0)], "ACGT")])
     # a query whose column codes no longer fit the LDS next to the row window
