@@ -2465,7 +2465,12 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             // map workspace): 15 % of what is free, at least 16 GB -- two processes sharing a GPU otherwise starve each other
             const uint64_t have = free_b + W.pool_size;
             const uint64_t reserve = std::max<uint64_t>((uint64_t)((double)have * 0.15), 16ull << 30);
-            const uint64_t avail = have > reserve ? have - reserve : have / 4;
+            uint64_t avail = have > reserve ? have - reserve : have / 4;
+            // several contexts on one GPU (vgaligner map --devices 0,0: the driver sets this to 1 / their number) share it
+            if (const char *fr = getenv("VGA_POOL_FRACTION")) {
+                const double f = atof(fr);
+                if (f > 0.0 && f < 1.0) avail = (uint64_t)((double)avail * f);
+            }
             const uint64_t target = std::min(std::max<uint64_t>(2 * want, 8ull << 30), avail) & ~(POA_CHUNK - 1);
             if (target > W.pool_size) {
                 if (W.pool) { (void)hipFree(W.pool); W.pool = nullptr; W.pool_size = 0; }

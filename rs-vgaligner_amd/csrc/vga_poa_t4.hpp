@@ -270,6 +270,9 @@ __global__ __launch_bounds__(NT, 4) void k_poa_dp_t4(
         // the wave that sets the row up rotates with the row (its state is in LDS): one wave per SIMD, so the set-up
         // work is spread over the CU's four SIMDs instead of making the first one the bottleneck
         if (wv == (int)(r % (uint32_t)NW)) {
+            // (the other waves of the workgroup wait for this block: let it win the issue arbitration against the waves of
+            // the other workgroups on its SIMD)
+            __builtin_amdgcn_s_setprio(3);
             // the previous row's maximum: combine the waves' results (only this wave needs them: the band, and the row record)
             int prev_lmax = 0, prev_rmax = 0;
             if (r > 0) {
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(NT, 4) void k_poa_dp_t4(
                 sRow[1] = make_int4((int)(uint32_t)voff, (int)(uint32_t)(voff >> 32), pbeg, pend);
                 sRow[2] = make_int4((int)(uint32_t)vpo, (int)(uint32_t)(vpo >> 32), L.failed, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         POA_LDS_BARRIER();
         POA_MARK("row_pickup");

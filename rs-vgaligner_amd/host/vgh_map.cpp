@@ -357,6 +357,12 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
         }
     }
     const uint32_t n_slots = (uint32_t)ctxs.size();
+    // contexts that share a GPU share its memory: each takes its part of the traceback pool
+    if (!devs.empty() && !getenv("VGA_POOL_FRACTION")) {
+        size_t most = 1;
+        for (int d : devs) most = std::max<size_t>(most, (size_t)std::count(devs.begin(), devs.end(), d));
+        if (most > 1) setenv("VGA_POOL_FRACTION", std::to_string(1.0 / (double)most).c_str(), 0);
+    }
     {
         vga_index_desc d;
         Index::DescScratch sc;
