@@ -277,6 +277,8 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     }
     read_prob0[R] = prob_read.size();
     const uint64_t n = prob_read.size();
+    // slot_of[q]: where the q-th (read, chain) pair of the list above sits in the launch order (filled below)
+    std::vector<uint32_t> slot_of(n);
 
     // ---- subgraphs: built by the host threads on request, one sub-batch ahead of the GPU (see poa_feed).  The launch
     // order is fixed up front from the span of each chain on the linearised graph.
@@ -320,6 +322,22 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
             q_src[p] = b->read_off[r];
         }
     });
+    // Launch order = largest footprint first (poa_run's stable sort by proxy).  The device store is filled in that order,
+    // in two parts: what the first launch takes before it, the rest beside it -- so the problems are permuted into launch
+    // order here and poa_run's sort keeps them.
+    for (uint64_t q = 0; q < n; q++) slot_of[q] = (uint32_t)q;
+    if (on_device && n > 1) {
+        std::vector<uint32_t> ord(n);
+        for (uint64_t q = 0; q < n; q++) ord[q] = (uint32_t)q;
+        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return proxy[x] > proxy[y]; });
+        auto permute = [&](auto &v) {
+            auto w = v;
+            for (uint64_t i = 0; i < n; i++) w[i] = v[ord[i]];
+            v.swap(w);
+        };
+        permute(prob_read); permute(prob_chain); permute(proxy); permute(feed.views); permute(descs); permute(q_src);
+        for (uint64_t i = 0; i < n; i++) slot_of[ord[i]] = (uint32_t)i;
+    }
     if (has_reverse)
         return vga_set_error(ctx, VGA_ERR_UNSUPPORTED,
                              "a chain to be aligned holds reverse-strand anchors: RangeOrient::Reverse / Both (src/align.rs:365-387) is not supported");
@@ -335,13 +353,22 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         vga_timers_reset(ctx);
         feed.keep_timers = true;
         auto ta = std::chrono::steady_clock::now();
-        const int rc = sg_prepare(ctx, descs.data(), q_src.data(), n, b->d_reads, store);
+        // the first launch takes 2 048 problems (poa_run, arena mode); small calls are prepared in one go
+        uint64_t split = n > 3072 ? 2048 : n;
+        if (const char *e = getenv("VGA_SG_SPLIT")) { const long v = atol(e); split = v <= 0 ? n : std::min<uint64_t>(n, (uint64_t)v); }  // (0: one part)
+        const int rc = sg_prepare(ctx, descs.data(), q_src.data(), n, split, b->d_reads, store);
         if (rc != VGA_OK) return rc;
         sub_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
         feed.dev = &store;
+        feed.dev_rest = [&]() -> int {
+            auto tb = std::chrono::steady_clock::now();
+            const int rc2 = sg_prepare_rest(ctx, store);
+            sub_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
+            return rc2;
+        };
         // base `off` of the node-th handle of problem p (seq_from_handle, src/index.rs:503-533)
         feed.row_base = [&](uint64_t p, uint32_t node, uint32_t off) -> char {
-            const handle_t h = store.h_handles[store.off[p].node0 + node];
+            const handle_t h = store.of(p).h_handles[store.off[p].node0 + node];
             const uint32_t id = h >> 1, s = ctx->index.node_start[id - 1], e = ctx->index.node_start[id];
             return (h & 1) ? iv_all.complement(ctx->index.seq_fwd[e - 1 - off]) : ctx->index.seq_fwd[s + off];
         };
@@ -398,7 +425,8 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     std::vector<uint32_t> path_n(R, 0);
     vga_parallel_for(R, [&](uint64_t r) {
         int64_t best = -1;
-        for (uint64_t p = read_prob0[r]; p < read_prob0[r + 1]; p++) {
+        for (uint64_t q = read_prob0[r]; q < read_prob0[r + 1]; q++) {
+            const uint64_t p = slot_of[q];
             if (!items[p].ok) continue;
             if (best < 0 || items[p].rows.size() > items[best].rows.size()) best = (int64_t)p;
         }
@@ -437,7 +465,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         uint64_t o = res->path_off[r];
         for (size_t t = 0; t < it.gnodes.size(); t++)
             if (t == 0 || it.gnodes[t] != it.gnodes[t - 1])  // align.rs:1120-1123
-                res->path_handles[o++] = on_device ? store.h_handles[store.off[p].node0 + it.gnodes[t]] : SG[p].handles[it.gnodes[t]];
+                res->path_handles[o++] = on_device ? store.of(p).h_handles[store.off[p].node0 + it.gnodes[t]] : SG[p].handles[it.gnodes[t]];
         res->path_length[r] = (uint32_t)it.rows.size();
         res->path_start[r] = it.start_off;
         res->path_end[r] = it.end_off;

@@ -2162,7 +2162,7 @@ static inline size_t poa_lds_bytes(uint32_t lds_cols, int nt)
 // store of vga_subgraph.hip (and the batch's reads) to where this sub-batch's poa_prob says they are.
 // ids: per staged problem its index in the store and its number of predecessor entries
 __global__ __launch_bounds__(256) void k_sg_gather(const uint32_t *__restrict__ ids, const poa_prob *__restrict__ probs, const sg_off *__restrict__ offs,
-                                                   const uint4 *__restrict__ s_ntab, const uint32_t *__restrict__ s_preds,
+                                                   uint32_t part_p0, const uint4 *__restrict__ s_ntab, const uint32_t *__restrict__ s_preds,
                                                    const uint32_t *__restrict__ s_sinks, const char *__restrict__ s_seq, const char *__restrict__ reads,
                                                    uint4 *ntab, uint32_t *preds, uint32_t *sinks, char *seq, char *q)
 {
@@ -2170,7 +2170,7 @@ __global__ __launch_bounds__(256) void k_sg_gather(const uint32_t *__restrict__ 
     const poa_prob pb = probs[blockIdx.x];
     const sg_off of = offs[p];
     const int tid = threadIdx.x;
-    const uint4 *a = s_ntab + of.node0 + p;
+    const uint4 *a = s_ntab + of.node0 + (p - part_p0);  // (a part's node tables carry one source entry per problem of the part)
     for (uint32_t i = (uint32_t)tid; i < pb.n_nodes; i += 256) ntab[pb.node0 + i] = a[i];
     for (uint32_t i = (uint32_t)tid; i < n_preds; i += 256) preds[pb.pred0 + i] = s_preds[of.pred0 + i];
     for (uint32_t i = (uint32_t)tid; i < pb.n_sink; i += 256) sinks[pb.sink0 + i] = s_sinks[of.sink0 + i];
@@ -2389,7 +2389,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         if (excess < 0) excess = -excess;
         return std::min((double)g.qlen + 1.0, 2.0 * w + 1.0 + 430.0 + 0.3 * excess);
     };
-    bool malformed = false;
+    bool malformed = false, dev_failed = false;
+    int dev_rc = VGA_OK;
     // prepares launch positions [a, b): the caller's part (subgraphs), then node tables and estimates
     std::vector<uint32_t> ids;
     auto ensure = [&](uint64_t a, uint64_t b) {
@@ -2398,6 +2399,13 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             if (!ready[order[i]]) ids.push_back(order[i]);
         if (ids.empty()) return;
         if (feed.prepare) feed.prepare(ids.data(), ids.size());
+        if (feed.dev && !feed.dev->part[1].ready) {
+            // the second part of the device store is built when a problem of it is first needed -- by then the first DP
+            // launch is on the GPU and the subgraph kernels run beside it
+            bool need = false;
+            for (uint32_t p : ids) need |= p >= feed.dev->split;
+            if (need && (dev_rc = feed.dev_rest()) != VGA_OK) { dev_failed = true; return; }
+        }
         parallel_for(ids.size(), [&](uint64_t t) {
             const uint32_t p = ids[t];
             if (feed.dev) {
@@ -2407,7 +2415,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 g.ok = !(sm.flags & 1u) && sm.n_nodes > 0 && views[p].qlen < (1u << 24);
                 g.N = sm.N; g.qlen = views[p].qlen; g.longest = (int32_t)sm.longest; g.life = sm.life;
                 g.n_ntab = sm.n_nodes + 1; g.n_preds = sm.n_preds; g.n_sinks = sm.n_sinks;
-                g.first_row_p = feed.dev->h_first_row + feed.dev->off[p].node0;
+                g.first_row_p = feed.dev->of(p).h_first_row + feed.dev->off[p].node0;
             } else
                 poa_prepare(views[p], G[p]);
             // footprint in the pool: a direction byte per cell plus the value-row ring (packed kernel)
@@ -2583,9 +2591,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         const double budget = (double)half_pool * 0.92;
         double used_est = 0, raw_est = 0, cells_est = 0;
         uint64_t i1 = i0;
+        // (device store: a launch gathers from one part of it)
+        if (feed.dev && feed.dev->split > i0 && feed.dev->split < cap) cap = feed.dev->split;
         while (i1 < cap) {
             if (!ready[order[i1]]) ensure(i1, std::min<uint64_t>(cap, i1 + 256));
-            if (malformed) break;
+            if (malformed || dev_failed) break;
             const double e = est[order[i1]] * W.pool_scale + 3.0 * (double)POA_CHUNK;
             if (!arena && i1 > i0 && used_est + e > budget) break;
             // the pool is not the only reason to cut: the host work either side of a sub-batch (subgraphs and node
@@ -2601,7 +2611,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         bool sub_h16 = false;  // this sub-batch runs the 16-bit DP kernel
         bool sub_t4 = false;   // ... k_poa_dp_t4 (its own direction-byte encoding)
         bool sub_fused = false;  // ... and its DP kernel does the traceback as well
-        if (malformed || i1 == i0) return {i0, i0, 0.0, slot, 0};
+        if (malformed || dev_failed || i1 == i0) return {i0, i0, 0.0, slot, 0};
         const int oset = (int)(S.uses++ & 1u);
         poa_slot::out_set &O = S.outs[oset];
         const uint32_t nb = (uint32_t)(i1 - i0);
@@ -2648,7 +2658,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             chk(hipMemcpyAsync(S.d_probs.p, S.h_probs.p, nb * sizeof(poa_prob), hipMemcpyHostToDevice, st));
             chk(hipMemcpyAsync(S.d_ids.p, S.h_ids.p, 2 * (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             const sg_store &D = *feed.dev;
-            hipLaunchKernelGGL(k_sg_gather, dim3(nb), dim3(256), 0, st, S.d_ids.p, S.d_probs.p, D.d_off, D.d_ntab, D.d_preds, D.d_sinks, D.d_seq, D.d_reads,
+            const sg_part &DP = D.of(order[i0]);
+            hipLaunchKernelGGL(k_sg_gather, dim3(nb), dim3(256), 0, st, S.d_ids.p, S.d_probs.p, D.d_off, (uint32_t)DP.p0, DP.d_ntab, DP.d_preds, DP.d_sinks, DP.d_seq, D.d_reads,
                                S.d_ntab.p, S.d_preds.p, S.d_sink.p, (char *)S.d_seq32.p, S.d_q.p);
         } else {
             parallel_for(nb, [&](uint64_t t) {
@@ -2967,7 +2978,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     bool slot_busy[POA_SLOTS] = {};
     uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
     auto fill = [&]() {
-        while ((int)inflight.size() < n_slots && !todo.empty() && !malformed && launch_err == hipSuccess) {
+        while ((int)inflight.size() < n_slots && !todo.empty() && !malformed && !dev_failed && launch_err == hipSuccess) {
             int slot = 0;
             while (slot_busy[slot]) slot++;
             auto &seg = todo.back();
@@ -3088,6 +3099,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     (void)hipStreamSynchronize(st);
     if (launch_err != hipSuccess) return vga_set_error(ctx, VGA_ERR_HIP, "POA launch failed: %s", hipGetErrorString(launch_err));
     if (malformed) return malformed_error();
+    if (dev_failed) return dev_rc;  // (sg_prepare_rest has set the message)
     vga_timer_end(ctx, t_total);
     tr.mark("dp + traceback + cigar (pipelined sub-batches)");
     if (rc_final != VGA_OK)

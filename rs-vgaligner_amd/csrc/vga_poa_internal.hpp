@@ -48,6 +48,7 @@ struct poa_feed {
     std::function<void(const uint32_t *ids, uint64_t cnt)> prepare;
     const double *proxy = nullptr;
     const sg_store *dev = nullptr;
+    std::function<int()> dev_rest;  // prepares the store's second part (problems >= dev->split); called once, when they are first needed
     std::function<char(uint64_t p, uint32_t node, uint32_t off)> row_base;
     bool keep_timers = false;  // the caller has reset the context's kernel timers and recorded some of its own
 };

@@ -407,22 +407,97 @@ __global__ __launch_bounds__(64) void k_sg_emit(uint32_t n, sg_index ix, uint32_
     }
 }
 
+struct sg_part_bufs {
+    vga_dbuf<uint32_t> d_handles, d_first_row, d_preds, d_sinks;
+    vga_dbuf<uint4> d_ntab;
+    vga_dbuf<char> d_seq;
+    vga_hbuf<uint32_t> h_handles, h_first_row;
+};
 struct sg_ws {
     vga_dbuf<sg_desc> d_desc;
     vga_dbuf<sg_sum> d_sum;
     vga_dbuf<sg_off> d_off;
-    vga_dbuf<uint32_t> d_bitmaps, d_scratch, d_handles, d_first_row, d_preds, d_sinks;
-    vga_dbuf<uint4> d_ntab;
-    vga_dbuf<char> d_seq;
+    vga_dbuf<uint32_t> d_bitmaps, d_scratch;
     vga_hbuf<sg_desc> h_desc;
     vga_hbuf<sg_sum> h_sum;
     vga_hbuf<sg_off> h_off;
-    vga_hbuf<uint32_t> h_handles, h_first_row;
+    sg_part_bufs part[2];
+    std::vector<uint64_t> q_src;
+    hipStream_t side = nullptr;
+    uint64_t waves = 0;
+    uint32_t nh = 0, words = 0;
+    ~sg_ws()
+    {
+        if (side) (void)hipStreamDestroy(side);
+    }
 };
+
+#define SG_CHECK(call)                                                                                                              \
+    do {                                                                                                                            \
+        hipError_t e_ = (call);                                                                                                     \
+        if (e_ != hipSuccess)                                                                                                       \
+            return vga_set_error(ctx, e_ == hipErrorOutOfMemory ? VGA_ERR_NOMEM : VGA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                                 __FILE__, __LINE__);                                                                               \
+    } while (0)
+
+// mark + counts, offsets, emit and the copies back for problems [p0, p1) on stream st; waits for them
+int sg_run_part(vga_ctx *ctx, sg_ws &W, sg_store &store, int k, uint64_t p0, uint64_t p1, hipStream_t st)
+{
+    sg_part &P = store.part[k];
+    P.p0 = p0; P.p1 = p1;
+    P.ready = true;
+    if (p1 <= p0) return VGA_OK;
+    const uint64_t n = p1 - p0;
+    const vga_dev_index &dix = ctx->index;
+    sg_index ix = {dix.d_node_start, dix.d_edge_idx, dix.d_edges_to, dix.d_edges, dix.d_seq_fwd, (uint32_t)dix.n_nodes};
+    const uint32_t nh = W.nh, words = W.words;
+    // the part that runs beside a DP launch keeps to two waves per CU: its waves are long-lived and every one of them
+    // takes registers a DP workgroup (four waves at once) is waiting for -- 4 096 of them halve the DP's occupancy
+    uint32_t waves = (uint32_t)std::min<uint64_t>(W.waves, n);
+    if (k == 1) {
+        uint32_t side_waves = 2u * (uint32_t)ctx->n_cu;  // (512: +3.7 % over one part on config 3; 256 starves the later launches, 1 024 and more slow the first)
+        if (const char *e = getenv("VGA_SG_SIDE_WAVES")) side_waves = (uint32_t)std::max(1, atoi(e));
+        waves = std::min(waves, side_waves);
+    }
+    sg_part_bufs &B = W.part[k];
+    int t_mark = vga_timer_begin(ctx, "subgraph_mark", 0, st);
+    hipLaunchKernelGGL(k_sg_mark, dim3(waves), dim3(64), 0, st, W.d_desc.p + p0, (uint32_t)n, ix, dix.k, words, nh, W.d_bitmaps.p + p0 * words,
+                       W.d_scratch.p, W.d_sum.p + p0);
+    vga_timer_end(ctx, t_mark);
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipMemcpyAsync(W.h_sum.p + p0, W.d_sum.p + p0, n * sizeof(sg_sum), hipMemcpyDeviceToHost, st));
+    SG_CHECK(hipStreamSynchronize(st));
+    uint64_t tn = 0, tp = 0, ts = 0, tq = 0;
+    for (uint64_t p = p0; p < p1; p++) {
+        const sg_sum &s = W.h_sum.p[p];
+        sg_off &o = W.h_off.p[p];
+        o.node0 = tn; o.pred0 = tp; o.sink0 = ts; o.seq0 = tq; o.q_src = W.q_src[p];
+        if (s.flags & 1u) continue;
+        tn += s.n_nodes; tp += s.n_preds; ts += s.n_sinks; tq += ((uint64_t)s.N + 3) & ~3ull;
+    }
+    SG_CHECK(B.d_handles.reserve(tn + 1)); SG_CHECK(B.d_first_row.reserve(tn + 1)); SG_CHECK(B.d_ntab.reserve(tn + n));
+    SG_CHECK(B.d_preds.reserve(tp + 1)); SG_CHECK(B.d_sinks.reserve(ts + 1)); SG_CHECK(B.d_seq.reserve(tq + 4));
+    SG_CHECK(B.h_handles.reserve(tn + 1)); SG_CHECK(B.h_first_row.reserve(tn + 1));
+    SG_CHECK(hipMemcpyAsync(W.d_off.p + p0, W.h_off.p + p0, n * sizeof(sg_off), hipMemcpyHostToDevice, st));
+    int t_emit = vga_timer_begin(ctx, "subgraph_emit", 0, st);
+    hipLaunchKernelGGL(k_sg_emit, dim3(waves), dim3(64), 0, st, (uint32_t)n, ix, words, nh, W.d_bitmaps.p + p0 * words, W.d_scratch.p, W.d_sum.p + p0,
+                       W.d_off.p + p0, B.d_handles.p, B.d_first_row.p, B.d_ntab.p, B.d_preds.p, B.d_sinks.p, B.d_seq.p);
+    vga_timer_end(ctx, t_emit);
+    SG_CHECK(hipGetLastError());
+    SG_CHECK(hipMemcpyAsync(W.h_sum.p + p0, W.d_sum.p + p0, n * sizeof(sg_sum), hipMemcpyDeviceToHost, st));
+    if (tn) {
+        SG_CHECK(hipMemcpyAsync(B.h_handles.p, B.d_handles.p, tn * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        SG_CHECK(hipMemcpyAsync(B.h_first_row.p, B.d_first_row.p, tn * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
+    SG_CHECK(hipStreamSynchronize(st));
+    P.d_ntab = B.d_ntab.p; P.d_preds = B.d_preds.p; P.d_sinks = B.d_sinks.p; P.d_seq = B.d_seq.p;
+    P.h_handles = B.h_handles.p; P.h_first_row = B.h_first_row.p;
+    return VGA_OK;
+}
 
 }  // namespace
 
-int sg_prepare(vga_ctx *ctx, const sg_desc *descs, const uint64_t *q_src, uint64_t n, const char *d_reads, sg_store &store)
+int sg_prepare(vga_ctx *ctx, const sg_desc *descs, const uint64_t *q_src, uint64_t n, uint64_t split, const char *d_reads, sg_store &store)
 {
     store = sg_store();
     if (n == 0) return VGA_OK;
@@ -434,61 +509,39 @@ int sg_prepare(vga_ctx *ctx, const sg_desc *descs, const uint64_t *q_src, uint64
         ctx->sg_ws_free = [](void *q) { delete (sg_ws *)q; };
     }
     sg_ws &W = *(sg_ws *)ctx->sg_ws;
+    if (!W.side) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        (void)hi;
+        SG_CHECK(hipStreamCreateWithPriority(&W.side, hipStreamNonBlocking, lo));  // (lowest priority: it must not displace DP workgroups)
+    }
     const vga_dev_index &dix = ctx->index;
-    sg_index ix = {dix.d_node_start, dix.d_edge_idx, dix.d_edges_to, dix.d_edges, dix.d_seq_fwd, (uint32_t)dix.n_nodes};
-    const uint32_t nh = 2u * ((uint32_t)dix.n_nodes + 2u);
-    const uint32_t words = (nh + 31u) / 32u;
+    W.nh = 2u * ((uint32_t)dix.n_nodes + 2u);
+    W.words = (W.nh + 31u) / 32u;
     // waves in flight: enough to hide the latency of the pointer chasing, bounded by the scratch they need (5 words per handle)
     uint64_t waves = std::min<uint64_t>(n, 16ull * (uint64_t)ctx->n_cu);
-    const uint64_t slab = 5ull * nh * sizeof(uint32_t);
-    waves = std::max<uint64_t>(1, std::min<uint64_t>(waves, (4ull << 30) / slab));
-#define SG_CHECK(call)                                                                                                              \
-    do {                                                                                                                            \
-        hipError_t e_ = (call);                                                                                                     \
-        if (e_ != hipSuccess)                                                                                                       \
-            return vga_set_error(ctx, e_ == hipErrorOutOfMemory ? VGA_ERR_NOMEM : VGA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
-                                 __FILE__, __LINE__);                                                                               \
-    } while (0)
+    const uint64_t slab = 5ull * W.nh * sizeof(uint32_t);
+    W.waves = std::max<uint64_t>(1, std::min<uint64_t>(waves, (4ull << 30) / slab));
+    if (split > n) split = n;
     SG_CHECK(W.d_desc.reserve(n)); SG_CHECK(W.d_sum.reserve(n)); SG_CHECK(W.d_off.reserve(n));
     SG_CHECK(W.h_desc.reserve(n)); SG_CHECK(W.h_sum.reserve(n)); SG_CHECK(W.h_off.reserve(n));
-    SG_CHECK(W.d_bitmaps.reserve(n * words));
-    SG_CHECK(W.d_scratch.reserve(waves * 5ull * nh));
+    SG_CHECK(W.d_bitmaps.reserve(n * W.words));
+    SG_CHECK(W.d_scratch.reserve(W.waves * 5ull * W.nh));
     memcpy(W.h_desc.p, descs, n * sizeof(sg_desc));
+    W.q_src.assign(q_src, q_src + n);
     SG_CHECK(hipMemcpyAsync(W.d_desc.p, W.h_desc.p, n * sizeof(sg_desc), hipMemcpyHostToDevice, st));
-    int t_mark = vga_timer_begin(ctx, "subgraph_mark", 0, st);
-    hipLaunchKernelGGL(k_sg_mark, dim3((uint32_t)waves), dim3(64), 0, st, W.d_desc.p, (uint32_t)n, ix, dix.k, words, nh, W.d_bitmaps.p, W.d_scratch.p, W.d_sum.p);
-    vga_timer_end(ctx, t_mark);
-    SG_CHECK(hipGetLastError());
-    SG_CHECK(hipMemcpyAsync(W.h_sum.p, W.d_sum.p, n * sizeof(sg_sum), hipMemcpyDeviceToHost, st));
-    SG_CHECK(hipStreamSynchronize(st));
-    uint64_t tn = 0, tp = 0, ts = 0, tq = 0;
-    for (uint64_t p = 0; p < n; p++) {
-        const sg_sum &s = W.h_sum.p[p];
-        sg_off &o = W.h_off.p[p];
-        o.node0 = tn; o.pred0 = tp; o.sink0 = ts; o.seq0 = tq; o.q_src = q_src[p];
-        if (s.flags & 1u) continue;
-        tn += s.n_nodes; tp += s.n_preds; ts += s.n_sinks; tq += ((uint64_t)s.N + 3) & ~3ull;
-    }
-    SG_CHECK(W.d_handles.reserve(tn + 1)); SG_CHECK(W.d_first_row.reserve(tn + 1)); SG_CHECK(W.d_ntab.reserve(tn + n));
-    SG_CHECK(W.d_preds.reserve(tp + 1)); SG_CHECK(W.d_sinks.reserve(ts + 1)); SG_CHECK(W.d_seq.reserve(tq + 4));
-    SG_CHECK(W.h_handles.reserve(tn + 1)); SG_CHECK(W.h_first_row.reserve(tn + 1));
-    SG_CHECK(hipMemcpyAsync(W.d_off.p, W.h_off.p, n * sizeof(sg_off), hipMemcpyHostToDevice, st));
-    int t_emit = vga_timer_begin(ctx, "subgraph_emit", 0, st);
-    hipLaunchKernelGGL(k_sg_emit, dim3((uint32_t)waves), dim3(64), 0, st, (uint32_t)n, ix, words, nh, W.d_bitmaps.p, W.d_scratch.p, W.d_sum.p, W.d_off.p,
-                       W.d_handles.p, W.d_first_row.p, W.d_ntab.p, W.d_preds.p, W.d_sinks.p, W.d_seq.p);
-    vga_timer_end(ctx, t_emit);
-    SG_CHECK(hipGetLastError());
-    SG_CHECK(hipMemcpyAsync(W.h_sum.p, W.d_sum.p, n * sizeof(sg_sum), hipMemcpyDeviceToHost, st));
-    if (tn) {
-        SG_CHECK(hipMemcpyAsync(W.h_handles.p, W.d_handles.p, tn * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        SG_CHECK(hipMemcpyAsync(W.h_first_row.p, W.d_first_row.p, tn * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    }
-    SG_CHECK(hipStreamSynchronize(st));
-#undef SG_CHECK
     store.n = n;
+    store.split = split;
     store.sum = W.h_sum.p; store.off = W.h_off.p; store.d_off = W.d_off.p;
-    store.d_ntab = W.d_ntab.p; store.d_preds = W.d_preds.p; store.d_sinks = W.d_sinks.p; store.d_seq = W.d_seq.p;
     store.d_reads = d_reads;
-    store.h_handles = W.h_handles.p; store.h_first_row = W.h_first_row.p;
-    return VGA_OK;
+    store.part[1].p0 = split; store.part[1].p1 = n;
+    return sg_run_part(ctx, W, store, 0, 0, split, st);
+}
+
+int sg_prepare_rest(vga_ctx *ctx, sg_store &store)
+{
+    if (store.part[1].ready) return VGA_OK;
+    (void)hipSetDevice(ctx->device);
+    sg_ws &W = *(sg_ws *)ctx->sg_ws;
+    return sg_run_part(ctx, W, store, 1, store.split, store.n, W.side);
 }

@@ -36,20 +36,29 @@ struct sg_off {
     uint64_t q_src;  // first base of the query in the batch's device copy of the reads
 };
 
-// the prepared problems of one vga_align_batch call (device store + what the host needs of it)
-struct sg_store {
-    uint64_t n = 0;
-    const sg_sum *sum = nullptr;     // host, n entries
-    const sg_off *off = nullptr;     // host, n entries
-    const sg_off *d_off = nullptr;   // device copy
+// The prepared problems of one vga_align_batch call (device store + what the host needs of it).  The problems come in
+// launch order and are prepared in two parts: [0, split) before the first DP launch, [split, n) beside it on a stream
+// of its own (sg_prepare_rest), so that only the first part's kernels sit in front of the DP.
+struct sg_part {
+    uint64_t p0 = 0, p1 = 0;
     const uint4 *d_ntab = nullptr;
     const uint32_t *d_preds = nullptr, *d_sinks = nullptr;
     const char *d_seq = nullptr;
-    const char *d_reads = nullptr;
     const uint32_t *h_handles = nullptr, *h_first_row = nullptr;  // host copies (pinned), indexed from off[p].node0
+    bool ready = false;
+};
+struct sg_store {
+    uint64_t n = 0, split = 0;
+    const sg_sum *sum = nullptr;    // host, n entries (valid for a part once it is ready)
+    const sg_off *off = nullptr;    // host, n entries, offsets inside the problem's part
+    const sg_off *d_off = nullptr;  // device copy
+    const char *d_reads = nullptr;
+    sg_part part[2];
+    const sg_part &of(uint64_t p) const { return part[p >= split ? 1 : 0]; }
 };
 
-// Runs the extraction for n chains on ctx->stream and waits for it.  `store` points into the context's workspace and stays
-// valid until the next call.  Returns VGA_OK or a negative VGA_ERR_*.
-int sg_prepare(vga_ctx *ctx, const sg_desc *descs, const uint64_t *q_src, uint64_t n, const char *d_reads, sg_store &store);
-
+// Runs the extraction for chains [0, split) of n on ctx->stream and waits for it.  `store` points into the context's
+// workspace and stays valid until the next call.  Returns VGA_OK or a negative VGA_ERR_*.
+int sg_prepare(vga_ctx *ctx, const sg_desc *descs, const uint64_t *q_src, uint64_t n, uint64_t split, const char *d_reads, sg_store &store);
+// ... and for chains [split, n), on the workspace's side stream (it may run beside DP launches); waits for it.
+int sg_prepare_rest(vga_ctx *ctx, sg_store &store);
