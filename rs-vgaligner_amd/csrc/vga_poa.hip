@@ -2160,21 +2160,28 @@ static inline size_t poa_lds_bytes(uint32_t lds_cols, int nt)
 
 // One workgroup per staged problem: copies its node table, predecessor rows, sink rows, bases and query from the device
 // store of vga_subgraph.hip (and the batch's reads) to where this sub-batch's poa_prob says they are.
-// ids: per staged problem its index in the store and its number of predecessor entries
+// ids: per staged problem its index in the store and its number of predecessor entries.  The store has two parts
+// (problems below / from `split`); a re-run launch may hold problems of both.
+struct sg_gather_src {
+    const uint4 *ntab;
+    const uint32_t *preds, *sinks;
+    const char *seq;
+    uint32_t p0;
+};
 __global__ __launch_bounds__(256) void k_sg_gather(const uint32_t *__restrict__ ids, const poa_prob *__restrict__ probs, const sg_off *__restrict__ offs,
-                                                   uint32_t part_p0, const uint4 *__restrict__ s_ntab, const uint32_t *__restrict__ s_preds,
-                                                   const uint32_t *__restrict__ s_sinks, const char *__restrict__ s_seq, const char *__restrict__ reads,
+                                                   uint32_t split, sg_gather_src s0, sg_gather_src s1, const char *__restrict__ reads,
                                                    uint4 *ntab, uint32_t *preds, uint32_t *sinks, char *seq, char *q)
 {
     const uint32_t p = ids[2 * blockIdx.x], n_preds = ids[2 * blockIdx.x + 1];
     const poa_prob pb = probs[blockIdx.x];
     const sg_off of = offs[p];
+    const sg_gather_src S = p >= split ? s1 : s0;
     const int tid = threadIdx.x;
-    const uint4 *a = s_ntab + of.node0 + (p - part_p0);  // (a part's node tables carry one source entry per problem of the part)
+    const uint4 *a = S.ntab + of.node0 + (p - S.p0);  // (a part's node tables carry one source entry per problem of the part)
     for (uint32_t i = (uint32_t)tid; i < pb.n_nodes; i += 256) ntab[pb.node0 + i] = a[i];
-    for (uint32_t i = (uint32_t)tid; i < n_preds; i += 256) preds[pb.pred0 + i] = s_preds[of.pred0 + i];
-    for (uint32_t i = (uint32_t)tid; i < pb.n_sink; i += 256) sinks[pb.sink0 + i] = s_sinks[of.sink0 + i];
-    const uint32_t *sw = (const uint32_t *)(s_seq + of.seq0);  // (seq0 is a multiple of 4 on both sides)
+    for (uint32_t i = (uint32_t)tid; i < n_preds; i += 256) preds[pb.pred0 + i] = S.preds[of.pred0 + i];
+    for (uint32_t i = (uint32_t)tid; i < pb.n_sink; i += 256) sinks[pb.sink0 + i] = S.sinks[of.sink0 + i];
+    const uint32_t *sw = (const uint32_t *)(S.seq + of.seq0);  // (seq0 is a multiple of 4 on both sides)
     uint32_t *dw = (uint32_t *)(seq + pb.seq0);
     for (uint32_t i = (uint32_t)tid; i < (pb.N + 3) / 4; i += 256) dw[i] = sw[i];
     for (uint32_t i = (uint32_t)tid; i < pb.qlen; i += 256) q[pb.q0 + i] = reads[of.q_src + i];
@@ -2658,8 +2665,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             chk(hipMemcpyAsync(S.d_probs.p, S.h_probs.p, nb * sizeof(poa_prob), hipMemcpyHostToDevice, st));
             chk(hipMemcpyAsync(S.d_ids.p, S.h_ids.p, 2 * (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             const sg_store &D = *feed.dev;
-            const sg_part &DP = D.of(order[i0]);
-            hipLaunchKernelGGL(k_sg_gather, dim3(nb), dim3(256), 0, st, S.d_ids.p, S.d_probs.p, D.d_off, (uint32_t)DP.p0, DP.d_ntab, DP.d_preds, DP.d_sinks, DP.d_seq, D.d_reads,
+            const sg_gather_src g0 = {D.part[0].d_ntab, D.part[0].d_preds, D.part[0].d_sinks, D.part[0].d_seq, (uint32_t)D.part[0].p0};
+            const sg_gather_src g1 = {D.part[1].d_ntab, D.part[1].d_preds, D.part[1].d_sinks, D.part[1].d_seq, (uint32_t)D.part[1].p0};
+            hipLaunchKernelGGL(k_sg_gather, dim3(nb), dim3(256), 0, st, S.d_ids.p, S.d_probs.p, D.d_off, (uint32_t)D.split, g0, g1, D.d_reads,
                                S.d_ntab.p, S.d_preds.p, S.d_sink.p, (char *)S.d_seq32.p, S.d_q.p);
         } else {
             parallel_for(nb, [&](uint64_t t) {
