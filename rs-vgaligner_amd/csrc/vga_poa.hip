@@ -3060,6 +3060,19 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 const poa_out &ho = S.h_outs.p[i - cur.i0];
                 if (ho.t_end > ho.t_begin) { tb = std::min(tb, ho.t_begin); te = std::max(te, ho.t_end); tsum += ho.t_end - ho.t_begin; }
             }
+            {
+                // the longest-running workgroup of the launch: what a single problem costs (its rows are sequential)
+                uint64_t worst_i = cur.i0, worst_t = 0;
+                for (uint64_t i = cur.i0; i < cur.i1; i++) {
+                    const poa_out &ho = S.h_outs.p[i - cur.i0];
+                    if (ho.t_end > ho.t_begin && ho.t_end - ho.t_begin > worst_t) { worst_t = ho.t_end - ho.t_begin; worst_i = i; }
+                }
+                const poa_out &ho = S.h_outs.p[worst_i - cur.i0];
+                const poa_prep &g = G[order[worst_i]];
+                fprintf(stderr, "[vga-trace] poa:   slowest problem: %.1f ms for %u rows (%.2f us per row), %u nodes, %.1f M cells (mean width %.0f, widest %u), "
+                                "%.0f %% of them in kept rows, query %u\n", (double)worst_t / 1e5, g.N, (double)worst_t / 100.0 / (double)std::max(1u, g.N),
+                        g.n_ntab - 1, (double)ho.cells / 1e6, (double)ho.cells / (double)std::max(1u, g.N), ho.maxw, 100.0 * (double)ho.vcells / (double)std::max<uint64_t>(1, ho.cells), g.qlen);
+            }
             fprintf(stderr, "[vga-trace] poa: sub-batch [%llu, %llu) done, pool %.1f GB, widest row %u columns, worst width / estimate %.3f; "
                             "DP %.1f ms, mean %.1f workgroups resident, on GPU clock %.3f .. %.3f s\n",
                     (unsigned long long)cur.i0, (unsigned long long)cur.i1, (double)W.h_next.p[cur.slot] / 1e9, mx, worst,
