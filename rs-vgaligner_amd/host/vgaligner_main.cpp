@@ -117,7 +117,7 @@ int map_main(int argc, char **argv)
         }
         if (o.devices.empty()) throw Error("--devices needs a comma-separated list of GPU ids");
     } else if (m.count("device")) o.devices.push_back(o.device);
-    o.chunk_reads = std::stoull(opt(m, "chunk-reads", "16384"));
+    o.chunk_reads = std::stoull(opt(m, "chunk-reads", "32768"));
     o.keep_text = o.write_console || o.also_validate;
     MapOutput out = map_reads_multi(ix, reads, o, prefix);
     fprintf(stderr, "[vgaligner] %llu GPU context(s), %llu batch(es)\n", (unsigned long long)out.n_devices, (unsigned long long)out.n_chunks);
@@ -137,7 +137,7 @@ int main(int argc, char **argv)
         if (argc >= 2 && !strcmp(argv[1], "map")) return map_main(argc, argv);
         fprintf(stderr, "vgaligner 0.7 (MI355X build)\nUSAGE:\n  vgaligner index -i <graph.gfa> -k <K> [-o prefix] [-e 100] [-m 100]\n"
                         "  vgaligner map -i <index> -f <reads.fa|fq> -p abpoa [-o prefix] [-g 1000] [-a 3] [-b 1] [-D -G <graph.gfa>] [-C]\n"
-                        "                [--devices 0,1,...] [--chunk-reads 16384]\n");
+                        "                [--devices 0,1,...] [--chunk-reads 32768]\n");
         return 2;
     } catch (const std::exception &e) {
         fprintf(stderr, "vgaligner: %s\n", e.what());

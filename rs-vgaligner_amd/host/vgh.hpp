@@ -117,7 +117,7 @@ struct MapOptions {
     // `devices` (an id may repeat: two contexts on one GPU), each mapping a contiguous slice of the reads balanced by bases, in
     // chunks of at most `chunk_reads` reads (0 = the whole slice at once) so that host and device memory stay bounded.
     std::vector<int> devices;
-    uint64_t chunk_reads = 16384;
+    uint64_t chunk_reads = 32768;
     // false: map_reads_multi writes the GAF files chunk by chunk and returns no text (the CLI without -C / -v); true: the
     // whole GAF text comes back in MapOutput
     bool keep_text = true;

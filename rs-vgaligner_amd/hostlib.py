@@ -116,7 +116,7 @@ class HostIndex:
         self.L.vgh_free(ag)
         return c, a, int(na.value)
 
-    def map_reads_multi(self, names: Sequence[str], seqs: Sequence[str], devices: Sequence[int] = (), chunk_reads: int = 16384,
+    def map_reads_multi(self, names: Sequence[str], seqs: Sequence[str], devices: Sequence[int] = (), chunk_reads: int = 32768,
                         max_gap: int = 1000, chain_min_n_anchors: int = 3, also_align: bool = True, align_best_n: int = 1,
                         out_prefix: Optional[str] = None) -> Tuple[str, str, int, int]:
         """vgh::map_reads_multi: one context + host thread per entry of `devices` (all visible GPUs when empty), contiguous
