@@ -288,6 +288,8 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     poa_feed feed;
     feed.views.resize(n);
     std::vector<double> proxy(n, 0.0);
+    std::vector<uint8_t> klass(n, 0);  // 1: a very long problem (by its actual rows, known for the first part of the store), launched apart
+    std::vector<uint32_t> launch_order(n);
     std::vector<sg_desc> descs(on_device ? n : 0);
     std::vector<uint64_t> q_src(on_device ? n : 0);
     std::atomic<int> has_reverse{0};
@@ -360,10 +362,23 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         if (rc != VGA_OK) return rc;
         sub_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
         feed.dev = &store;
+        // The rows of the first part's problems are known now.  Very long ones (config 3's longest have 21 000 rows; a chain
+        // that spans 100 kbp of the linearisation has 110 000, all sequential) decide how long the call takes: they go
+        // first, in a launch of their own with 512 threads and an 8 192-column window (poa_run).  The order inside the
+        // first part is free -- the store is addressed by problem index.
+        for (uint64_t i = 0; i < n; i++) launch_order[i] = (uint32_t)i;
+        for (uint64_t i = 0; i < store.split; i++) klass[i] = store.sum[i].N >= 40000u ? 1 : 0;
+        std::stable_sort(launch_order.begin(), launch_order.begin() + (long)store.split, [&](uint32_t x, uint32_t y) { return klass[x] > klass[y]; });
+        feed.order = launch_order.data();
+        feed.klass = klass.data();
         feed.dev_rest = [&]() -> int {
             auto tb = std::chrono::steady_clock::now();
             const int rc2 = sg_prepare_rest(ctx, store);
             sub_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
+            if (rc2 == VGA_OK) {  // none of the second part's problems has been staged yet: its very long ones move to its front
+                for (uint64_t i = store.split; i < n; i++) klass[i] = store.sum[i].N >= 40000u ? 1 : 0;
+                std::stable_sort(launch_order.begin() + (long)store.split, launch_order.end(), [&](uint32_t x, uint32_t y) { return klass[x] > klass[y]; });
+            }
             return rc2;
         };
         // base `off` of the node-th handle of problem p (seq_from_handle, src/index.rs:503-533)

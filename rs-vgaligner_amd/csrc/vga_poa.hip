@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 6)) void k_poa_dp_pk(
         if (win_mask != 0xFFFFFFFFu) L.wide_scratch = alloc(L, L.vcur, L.vendp, 2ull * VB * lds_cols);
         // The value row of a node's last base is read by the first rows of that node's successors only.  No edge spans
         // more than ring_rows - 1 nodes except the ones the host marked as long-lived (those rows are kept for good), so a
-        // ring of ring_rows worst-case rows never overwrites a row that is still needed -- and a problem holds ~1 MB of
+        // ring of ring_rows slots of one worst-case row each never overwrites a row that is still needed -- and a problem holds ~1 MB of
         // value rows instead of ~28 MB, which is what lets twice as many problems share the pool.
         {
             const uint64_t maxrow = ((uint64_t)VB * (uint64_t)((qlen + 8) & ~3) + 15ull) & ~15ull;
@@ -1194,8 +1194,8 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 6)) void k_poa_dp_pk(
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv);
             if (b + rb > pool_size || rb >= (1ull << 32)) L.failed = 1;
             L.ring_base = b;
-            L.ring_size = (uint32_t)(maxrow * (uint64_t)pb.ring_rows);
-            L.ring_head = 0;
+            L.ring_size = (uint32_t)maxrow;  // bytes per slot of the ring
+            L.ring_head = 0;                 // the slot the next node-end row takes
         }
         lead_store(L);
     }
@@ -1279,10 +1279,9 @@ __global__ __launch_bounds__(NT, (CPT == 8 ? 5 : 6)) void k_poa_dp_pk(
                 // kept for good: the source row (every root reads it) and rows that are read far ahead
                 if (r == 0 || (nt.z & 0x40000000u)) voff = alloc(L, L.vcur, L.vendp, (uint64_t)VB * (uint64_t)W);
                 else {
-                    const uint32_t bytes = ((uint32_t)VB * (uint32_t)W + 15u) & ~15u;
-                    if (L.ring_head + bytes > L.ring_size) L.ring_head = 0;
-                    voff = L.ring_base + L.ring_head;
-                    L.ring_head += bytes;
+                    // fixed slots of one worst-case row (see k_poa_dp_t4)
+                    voff = L.ring_base + (uint64_t)L.ring_head * L.ring_size;
+                    L.ring_head = L.ring_head + 1 == pb.ring_rows ? 0 : L.ring_head + 1;
                 }
             } else if (wide) voff = L.wide_scratch + (r & 1u) * (uint64_t)VB * lds_cols;
             int pbeg = prev_beg, pend = prev_end;
@@ -2411,7 +2410,17 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             // launch is on the GPU and the subgraph kernels run beside it
             bool need = false;
             for (uint32_t p : ids) need |= p >= feed.dev->split;
-            if (need && (dev_rc = feed.dev_rest()) != VGA_OK) { dev_failed = true; return; }
+            if (need) {
+                if ((dev_rc = feed.dev_rest()) != VGA_OK) { dev_failed = true; return; }
+                // the caller may have re-ordered the second part (none of it has been staged): take its order over, and
+                // prepare what now stands at the positions asked for
+                if (feed.order) {
+                    for (uint64_t i = feed.dev->split; i < n; i++) order[i] = feed.order[i];
+                    ids.clear();
+                    for (uint64_t i = a; i < b && i < order.size(); i++)
+                        if (!ready[order[i]]) ids.push_back(order[i]);
+                }
+            }
         }
         parallel_for(ids.size(), [&](uint64_t t) {
             const uint32_t p = ids[t];
@@ -2435,7 +2444,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         for (uint32_t p : ids)
             if (!G[p].ok) malformed = true;
     };
-    if (feed.proxy) {
+    if (feed.order) {
+        for (uint64_t p = 0; p < n; p++) order[p] = feed.order[p];
+    } else if (feed.proxy) {
         std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return feed.proxy[x] > feed.proxy[y]; });
     } else {
         ensure(0, n);
@@ -2534,7 +2545,14 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     // classic mode: two sub-batches in flight (three are no faster, four overflow their pool quarters).  Arena mode: the
     // pool is not split, a third slot only costs staging buffers and keeps the GPU fed while the oldest launch waits for
     // its slowest problems (+1.4 % on config 3, +4 % on config 4, same-box)
-    int n_slots = arena_wanted ? 3 : 2;
+    // Two launches in flight keep the GPU full when the problems of a call are of one kind (config 3: 8 410-8 460 reads/s
+    // with two, 8 100-8 370 with three, same-box); when the call holds very long problems (poa_feed::klass: config 4's
+    // 100 000-row chains) their launch occupies a slot for a second, and a third slot keeps two for everything else
+    // (config 4: 7 900 reads/s with three, 5 900 with two)
+    bool any_long = false;
+    if (feed.klass)
+        for (uint64_t p = 0; p < n && !any_long; p++) any_long = feed.klass[p] != 0;
+    int n_slots = arena_wanted ? (any_long || !feed.klass ? 3 : 2) : 2;
     if (const char *e = getenv("VGA_POA_SLOTS")) n_slots = std::max(1, std::min(POA_SLOTS, atoi(e)));
     hipStream_t sarr[POA_SLOTS];
     sarr[0] = st;
@@ -2608,6 +2626,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             // the pool is not the only reason to cut: the host work either side of a sub-batch (subgraphs and node
             // tables before, CIGAR / cs strings after) only overlaps with the GPU when there are several sub-batches
             if (i1 - i0 >= sub_problems && cells_est >= sub_cells) break;
+            // very long problems (a chain that spans 100 kbp of the linearisation: 100 000 sequential rows) are a launch of
+            // their own: they decide how long the whole call takes, so they get the largest workgroup and window (below)
+            if (feed.klass && i1 > i0 && feed.klass[order[i1]] != feed.klass[order[i0]]) break;
             used_est += e;
             // (arena mode: problems that are sent on to the classic pass take no arena and do not count)
             if (!arena || e * 1.1 <= (double)arena_size) raw_est += est[order[i1]];
@@ -2729,6 +2750,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                     while (w2 < 4096 && (double)w2 < mw * 1.25 + 16.0) w2 <<= 1;
                     want = w2;
                 }
+                if (feed.klass && feed.klass[order[i0]] && !getenv("VGA_POA_NO_GIANTS")) want = 8192;
                 const char *ew = getenv("VGA_POA_WINDOW");
                 if (ew) want = (uint32_t)strtoul(ew, nullptr, 10);
                 if (want >= 16 && (want & (want - 1)) == 0 && want < lds_cols) { hg_cols = want; win_mask = want - 1; }
@@ -2751,6 +2773,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 // narrow bands (one step of a 128-thread workgroup covers a typical row): the per-row set-up and the
                 // barriers dominate, and they are per wave -- config 5 (mean width 340): +6 % with 128 threads
                 if (mean_w <= 800.0) nt = 128;  // (the estimate is of a problem's widest rows: about twice its mean band)
+                if (feed.klass && feed.klass[order[i0]] && !getenv("VGA_POA_NO_GIANTS")) nt = 512;
                 const char *ent = getenv("VGA_POA_NT");
                 if (ent) nt = atoi(ent);
                 if (nt < 128 || nt > 512 || nt % 64) nt = 512;
@@ -3007,8 +3030,20 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     while (!inflight.empty()) {
         // look ahead: prepare the problems the next launch will start with while the GPU is busy
         if (!todo.empty()) ensure(todo.back().first, std::min<uint64_t>(todo.back().second, todo.back().first + 1536));
-        const sub_t cur = inflight.front();
-        inflight.erase(inflight.begin());
+        // the launch that finishes first is handled first: a launch of long problems (they come first in the order) must
+        // not keep the slots of the shorter ones behind it from being refilled
+        size_t pick = 0;
+        if (inflight.size() > 1) {
+            for (bool found = false; !found;) {
+                for (size_t q = 0; q < inflight.size() && !found; q++) {
+                    const hipError_t qe = hipStreamQuery(sarr[inflight[q].slot]);
+                    if (qe != hipErrorNotReady) { pick = q; found = true; }  // finished (or failed: the synchronize below reports it)
+                }
+                if (!found) std::this_thread::sleep_for(std::chrono::microseconds(100));
+            }
+        }
+        const sub_t cur = inflight[pick];
+        inflight.erase(inflight.begin() + (long)pick);
         {
             const hipError_t se = hipStreamSynchronize(sarr[cur.slot]);
             if (se != hipSuccess) { launch_err = se; break; }  // (falls through to the drain of every stream below)
@@ -3033,6 +3068,16 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             const double ratio = (double)W.h_next.p[cur.slot] / cur.raw_est;
             // conservative on purpose: a sub-batch that overflows its half takes its unfinished problems down with it
             W.pool_scale = std::max(ratio * 1.15, 0.6 * W.pool_scale + 0.4 * ratio * 1.25);
+        }
+        if (const char *dump = getenv("VGA_POA_DUMP_ROWS")) {  // diagnostics: the row records of the launch's first problem
+            const poa_prob &pb0 = probs[order[cur.i0]];
+            std::vector<poa_row> hr(pb0.N + 1);
+            (void)hipMemcpy(hr.data(), W.slot[cur.slot].d_rows.p + pb0.row0, hr.size() * sizeof(poa_row), hipMemcpyDeviceToHost);
+            FILE *f = fopen(dump, "w");
+            if (f) {
+                for (size_t r = 0; r < hr.size(); r++) fprintf(f, "%zu %d %d %d %d %u %u %llu\n", r, hr[r].beg, hr[r].end, hr[r].lmax, hr[r].rmax, hr[r].pred, hr[r].npred, (unsigned long long)hr[r].voff);
+                fclose(f);
+            }
         }
         if (tr.on) {
             double worst = 0;

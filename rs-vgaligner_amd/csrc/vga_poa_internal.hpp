@@ -50,6 +50,10 @@ struct poa_feed {
     const sg_store *dev = nullptr;
     std::function<int()> dev_rest;  // prepares the store's second part (problems >= dev->split); called once, when they are first needed
     std::function<char(uint64_t p, uint32_t node, uint32_t off)> row_base;
+    // optional: the launch order itself (n problem indices; poa_run then does not sort by proxy) and a class per problem
+    // (1 = very long: such problems are launched apart, with the largest workgroup and window)
+    const uint32_t *order = nullptr;
+    const uint8_t *klass = nullptr;
     bool keep_timers = false;  // the caller has reset the context's kernel timers and recorded some of its own
 };
 

@@ -229,8 +229,8 @@ __global__ __launch_bounds__(NT, 4) void k_poa_dp_t4(
                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bv);
             if (b + rb > pool_size || rb >= (1ull << 32)) L.failed = 1;
             L.ring_base = b;
-            L.ring_size = (uint32_t)(maxrow * (uint64_t)pb.ring_rows);
-            L.ring_head = 0;
+            L.ring_size = (uint32_t)maxrow;  // bytes per slot of the ring
+            L.ring_head = 0;                 // the slot the next node-end row takes
         }
         lead_store(L);
     }
@@ -337,10 +337,10 @@ __global__ __launch_bounds__(NT, 4) void k_poa_dp_t4(
             if (last && !L.failed) {
                 if (r == 0 || (nt.z & 0x40000000u)) voff = alloc(L, L.vcur, L.vendp, 6ull * (uint64_t)W);
                 else {
-                    const uint32_t bytes = (6u * (uint32_t)W + 15u) & ~15u;
-                    if (L.ring_head + bytes > L.ring_size) L.ring_head = 0;
-                    voff = L.ring_base + L.ring_head;
-                    L.ring_head += bytes;
+                    // fixed slots of one worst-case row: the rows of the last ring_rows node ends survive whatever their
+                    // widths (a byte ring that wraps when a row does not fit can overwrite the row written two slots ago)
+                    voff = L.ring_base + (uint64_t)L.ring_head * L.ring_size;
+                    L.ring_head = L.ring_head + 1 == pb.ring_rows ? 0 : L.ring_head + 1;
                 }
             } else if (wide) voff = L.wide_scratch + (r & 1u) * 6ull * lds_cols;
             int pbeg = prev_beg, pend = prev_end;

@@ -303,8 +303,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(W1_FIRST_STATE_V
     const uint64_t ring_bytes = (maxrow * (uint64_t)pb.ring_rows + POA_CHUNK - 1) & ~(POA_CHUNK - 1);
     const uint64_t ring_base = take(ring_bytes);
     if (ring_bytes >= (1ull << 32)) failed = true;
-    const uint32_t ring_size = (uint32_t)(maxrow * (uint64_t)pb.ring_rows);
-    uint32_t ring_head = 0;
+    uint32_t ring_head = 0;  // the slot of the ring the next node-end row takes (a slot = one worst-case row)
 
     int sink_best = POA_NEG, sink_have = 0;
     uint32_t sink_row = 0;
@@ -377,10 +376,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(W1_FIRST_STATE_V
         if (last) {
             if (r == 0 || (sfl & POA_RF_KEEP)) voff = bump(vcur, vend, 6ull * (uint64_t)W);
             else {
-                const uint32_t bytes = (6u * (uint32_t)W + 15u) & ~15u;
-                if (ring_head + bytes > ring_size) ring_head = 0;
-                voff = ring_base + ring_head;
-                ring_head += bytes;
+                voff = ring_base + (uint64_t)ring_head * maxrow;  // fixed slots (see k_poa_dp_t4)
+                ring_head = ring_head + 1 == pb.ring_rows ? 0 : ring_head + 1;
             }
         }
         if (failed) break;

@@ -156,6 +156,7 @@ def test_config3_whole_bench_batch(env):
     b = ctx.batch(seqs)
     al = b.align(b.map())
     assert int(al.aligned.sum()) == 10000
+    assert int(al.best_score.max()) <= 2 * 10100 and int(al.best_score.min()) > -60000  # (match 2 per base at best)
     for r in range(10000):
         runs = re.findall(r"(\d+)([MID])", al.cigar[r])
         nM = sum(int(n) for n, op in runs if op == "M")

@@ -284,6 +284,18 @@ def test_align_config3_sample(oracle, ctx, drb1):
     _check_align(oracle, ctx, ix, pkg().readsim.config3_reads(DRB1, 3))
 
 
+def test_value_row_ring_keeps_rows_of_unequal_width(oracle, ctx, drb1):
+    """Regression (round 2): node-end value rows live in a per-problem ring.  As a byte ring that wrapped whenever a row did
+    not fit, a run of rows of unequal width could overwrite the row written two slots earlier while a sibling allele still
+    had to read it -- read 1324 of this set (a poor alignment, score -296, whose rows span the whole query) came back
+    with a garbage score and a different band.  The ring now has fixed slots of one worst-case row."""
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    reads = pkg().readsim.simulate_reads(DRB1, 2000, 2500, 0.03, 0.03, 0.04, seed=4242)
+    al = _check_align(oracle, ctx, ix, reads[1316:1332])
+    assert int(al.best_score[8]) == -296
+
+
 def test_align_config4_merged_hla_sample(oracle, ctx, config4_gfa):
     """BASELINE config #4 (sample): reads from several loci of the merged HLA graph, full path length where the
     locus is shorter than 10 kbp; includes the one-node DRB5 locus (12.9 kbp in a single node)"""
