@@ -10,13 +10,14 @@ o.build()
 p = pkg()
 ctx = p.Context(0)
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+seed_off = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # other reads on every run: python tests/fuzz_align.py 6000 1000
 t0 = time.time()
 for gfa, seeds in ((os.path.join(DATA, "DRB1-3123.gfa"), (101, 102, 103)),):
     ix = o.Index(o.Graph.from_gfa(gfa), 11)
     upload_oracle_index(ctx, ix)
     for sd in seeds:
         L = {101: 1200, 102: 2500, 103: 4000}[sd]
-        reads = p.readsim.simulate_reads(gfa, n_reads // 3, L, 0.04, 0.05, 0.06, seed=sd)  # indel-heavy: the band's edges move a lot
+        reads = p.readsim.simulate_reads(gfa, n_reads // 3, L, 0.04, 0.05, 0.06, seed=sd + seed_off)  # indel-heavy: the band's edges move a lot
         T._check_align(o, ctx, ix, reads)
         print("reads of", L, "ok", round(time.time() - t0, 1), "s", flush=True)
 if n_reads >= 600:
@@ -27,10 +28,10 @@ if n_reads >= 600:
     for gfa in (hla, syn, os.path.join(DATA, "DRB1-3123.gfa")):
         ix = o.Index(o.Graph.from_gfa(gfa), 11)
         upload_oracle_index(ctx, ix)
-        T._check_align(o, ctx, ix, p.readsim.simulate_reads(gfa, 40, 10000, 0.03, 0.03, 0.04, seed=7))
-        T._check_align(o, ctx, ix, p.readsim.simulate_reads(gfa, 200, 700, 0.08, 0.06, 0.06, seed=8))
+        T._check_align(o, ctx, ix, p.readsim.simulate_reads(gfa, 40, 10000, 0.03, 0.03, 0.04, seed=7 + seed_off))
+        T._check_align(o, ctx, ix, p.readsim.simulate_reads(gfa, 200, 700, 0.08, 0.06, 0.06, seed=8 + seed_off))
         print(os.path.basename(gfa), "10 kbp + noisy short reads ok", round(time.time() - t0, 1), "s", flush=True)
-rng = random.Random(77)
+rng = random.Random(77 + seed_off)
 probs = [T._rand_problem(rng, rng.randint(5, 60), 12) for _ in range(400)]
 T._check_poa(o, ctx, probs)
 print("400 random POA problems ok", flush=True)
