@@ -35,3 +35,24 @@ rng = random.Random(77 + seed_off)
 probs = [T._rand_problem(rng, rng.randint(5, 60), 12) for _ in range(400)]
 T._check_poa(o, ctx, probs)
 print("400 random POA problems ok", flush=True)
+
+# chimeric / rearranged reads: a stretch of random bases, a large deletion or a large duplication inside a real read --
+# chains that cover part of the read, long extensions, rows that span the whole query, alignments with negative scores
+if n_reads >= 600:
+    gfa = os.path.join(DATA, "DRB1-3123.gfa")
+    ix = o.Index(o.Graph.from_gfa(gfa), 11)
+    upload_oracle_index(ctx, ix)
+    base = p.readsim.simulate_reads(gfa, n_reads // 6, 3000, 0.02, 0.02, 0.03, seed=55 + seed_off)
+    odd = []
+    for i, r in enumerate(base):
+        s = r.seq
+        a = rng.randint(100, len(s) - 1200)
+        k = i % 4
+        if k == 0: s = s[:a] + "".join(rng.choice("ACGT") for _ in range(rng.randint(300, 1500))) + s[a + 800:]
+        elif k == 1: s = s[:a] + s[a + rng.randint(400, 1000):]
+        elif k == 2: s = s[:a + 600] + s[a:a + 600] + s[a + 600:]
+        else: s = "".join(rng.choice("ACGT") for _ in range(rng.randint(200, 900))) + s[a:]
+        import dataclasses
+        odd.append(dataclasses.replace(r, seq=s))
+    T._check_align(o, ctx, ix, odd)
+    print(len(odd), "chimeric / rearranged reads ok", round(time.time() - t0, 1), "s", flush=True)
