@@ -169,9 +169,10 @@ struct vga_trace {
 // host thread fan-out (VGA_HOST_THREADS caps it; default: hardware concurrency, at most 32)
 unsigned vga_host_threads(uint64_t n);
 template <typename F>
-void vga_parallel_for(uint64_t n, F f)
+void vga_parallel_for(uint64_t n, F f, unsigned max_threads = 0)  // max_threads: a cap for small jobs (starting 32 threads costs ~0.7 ms)
 {
     unsigned nt = vga_host_threads(n);
+    if (max_threads && nt > max_threads) nt = max_threads;
     if (nt <= 1) { for (uint64_t i = 0; i < n; i++) f(i); return; }
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++)

@@ -793,7 +793,7 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
             case 4: memcpy(res->max_chain_score + lo, ws.h_f.p + lo, (hi - lo) * 8); break;
             default: memcpy(res->best_pred_id + lo, ws.h_pred.p + lo, (hi - lo) * 4); break;
             }
-        });
+        }, (unsigned)std::max<uint64_t>(1, An / 500000));  // (a thread per ~6 MB: small batches are not worth the thread start-up)
         memcpy(res->curr_max, ws.h_curr_max.p, R * 8);
     }
     const uint32_t *h_chain_cnt = ws.h_chain_cnt.p, *h_chain_words = ws.h_chain_words.p, *h_chain_buf = ws.h_chain_buf.p;
@@ -835,7 +835,7 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
             mi += len;
             ci++;
         }
-    });
+    }, (unsigned)std::max<uint64_t>(1, (n_members + 64 * R) / 1000000));
     tr.mark("chain assembly");
     res->ms_probe = vga_timer_sum(ctx, "kmer_probe");
     res->ms_sort = vga_timer_sum(ctx, "anchor_sort");
