@@ -147,7 +147,8 @@ def test_config3_full_length_alignments_are_self_consistent(env):
 
 def test_config3_whole_bench_batch(env):
     """BASELINE config #3 at the size the bench line is quoted on: 10 000 x 10 kbp reads in one batch.  Every read aligns;
-    every CIGAR consumes its read and spans its path; 400 alignments spread over the batch are replayed base by base; and
+    every CIGAR consumes its read and spans its path; 400 alignments spread over the batch are replayed base by base; 40
+    equal the oracle's records; and
     the records of the first 192 reads equal those of the 192-read batch (a read's result does not depend on the batch
     it travels in, whichever sub-batch, launch and arena it lands in)."""
     p, hi, ctx, arr = env
@@ -166,6 +167,17 @@ def test_config3_whole_bench_batch(env):
     edges_of = _edges_of(arr)
     for r in list(range(0, 10000, 27)) + list(range(9970, 10000)):
         _check_alignment(seqs[r], al, r, arr, edges_of)
+    # ... and 40 reads spread over the batch equal the oracle's records field for field (the oracle takes ~0.4 s per read)
+    from oracle import oracle_py as o
+    oix = o.Index(o.Graph.from_gfa(DRB1), 11)
+    pick = list(range(7, 10000, 250))
+    _, ag, _ = o.map_reads(oix, [reads[r].name for r in pick], [seqs[r] for r in pick])
+    for r, line in zip(pick, ag.splitlines()):
+        f = line.split("\t")
+        hs = al.path_handles[int(al.path_off[r]):int(al.path_off[r + 1])].tolist()
+        assert "".join((">" if not (h & 1) else "<") + str(h >> 1) for h in hs) == f[5], f"read {r}: node path"
+        assert f[12] == "as:i:-30 " + al.cs[r] + ",cg:Z:" + al.cigar[r], f"read {r}: cs / CIGAR"
+        assert (int(f[6]), int(f[7]), int(f[8]), int(f[10])) == (int(al.path_length[r]), int(al.path_start[r]), int(al.path_end[r]), int(al.block_length[r]))
     small = ctx.batch(seqs[:192])
     al_s = small.align(small.map())
     assert al_s.cigar == al.cigar[:192] and al_s.cs == al.cs[:192]
