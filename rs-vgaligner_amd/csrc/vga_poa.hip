@@ -2773,10 +2773,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 // narrow bands (one step of a 128-thread workgroup covers a typical row): the per-row set-up and the
                 // barriers dominate, and they are per wave -- config 5 (mean width 340): +6 % with 128 threads
                 if (mean_w <= 800.0) nt = 128;  // (the estimate is of a problem's widest rows: about twice its mean band)
-                if (feed.klass && feed.klass[order[i0]] && !getenv("VGA_POA_NO_GIANTS")) nt = 512;
+                if (feed.klass && feed.klass[order[i0]] && !getenv("VGA_POA_NO_GIANTS")) nt = getenv("VGA_POA_GIANT_NT") ? atoi(getenv("VGA_POA_GIANT_NT")) : 1024;  // (config 4: +5 % over 512, same-box)
                 const char *ent = getenv("VGA_POA_NT");
                 if (ent) nt = atoi(ent);
-                if (nt < 128 || nt > 512 || nt % 64) nt = 512;
+                if (nt < 128 || (nt > 512 && nt != 768 && nt != 1024) || nt % 64) nt = 512;
             }
             if (force) {
                 if (strstr(force, "128")) nt = 128;
@@ -2820,7 +2820,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         break;
                 switch (nt) {
                     POA_T4_LAUNCH(128) POA_T4_LAUNCH(192) POA_T4_LAUNCH(256) POA_T4_LAUNCH(320)
-                    POA_T4_LAUNCH(384) POA_T4_LAUNCH(448) POA_T4_LAUNCH(512)
+                    POA_T4_LAUNCH(384) POA_T4_LAUNCH(448) POA_T4_LAUNCH(512) POA_T4_LAUNCH(768) POA_T4_LAUNCH(1024)
                 default: chk(hipErrorInvalidValue);
                 }
 #undef POA_T4_LAUNCH

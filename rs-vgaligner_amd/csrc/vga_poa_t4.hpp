@@ -282,6 +282,7 @@ __global__ __launch_bounds__(NT, 4) void k_poa_dp_t4(
                 t = poa_dpp<0x111, 0xf>(INT32_MIN, b); b = t > b ? t : b;
                 if (NW > 2) { t = poa_dpp<0x112, 0xf>(INT32_MIN, b); b = t > b ? t : b; }
                 if (NW > 4) { t = poa_dpp<0x114, 0xf>(INT32_MIN, b); b = t > b ? t : b; }
+                if (NW > 8) { t = poa_dpp<0x118, 0xf>(INT32_MIN, b); b = t > b ? t : b; }
                 const int rbest = __builtin_amdgcn_readlane(b, NW - 1);
                 int lm = rw.x == rbest ? rw.y : INT32_MIN, rm = rw.x == rbest ? rw.z : INT32_MIN;
                 t = poa_dpp<0x111, 0xf>(INT32_MIN, lm); lm = t > lm ? t : lm;
@@ -293,6 +294,10 @@ __global__ __launch_bounds__(NT, 4) void k_poa_dp_t4(
                 if (NW > 4) {
                     t = poa_dpp<0x114, 0xf>(INT32_MIN, lm); lm = t > lm ? t : lm;
                     t = poa_dpp<0x114, 0xf>(INT32_MIN, rm); rm = t > rm ? t : rm;
+                }
+                if (NW > 8) {  // (up to 16 waves: 1 024 threads for the very long problems)
+                    t = poa_dpp<0x118, 0xf>(INT32_MIN, lm); lm = t > lm ? t : lm;
+                    t = poa_dpp<0x118, 0xf>(INT32_MIN, rm); rm = t > rm ? t : rm;
                 }
                 prev_lmax = -__builtin_amdgcn_readlane(lm, NW - 1);
                 prev_rmax = __builtin_amdgcn_readlane(rm, NW - 1);
