@@ -2543,8 +2543,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     const bool tb_fused = !getenv("VGA_POA_TB") || strstr(getenv("VGA_POA_TB"), "fused");
     const bool arena_wanted = packed_k && tb_fused && !getenv("VGA_POA_STAMPS") && !(getenv("VGA_POA_ARENAS") && atoi(getenv("VGA_POA_ARENAS")) == 0);
     // classic mode: two sub-batches in flight (three are no faster, four overflow their pool quarters).  Arena mode: the
-    // pool is not split, a third slot only costs staging buffers and keeps the GPU fed while the oldest launch waits for
-    // its slowest problems (+1.4 % on config 3, +4 % on config 4, same-box)
+    // pool is not split and a third slot only costs staging buffers (round 1 ran three throughout: +1.4 % on config 3 with
+    // first-in-first-out completion; with launches handled in the order they finish, round 2, that reversed).
     // Two launches in flight keep the GPU full when the problems of a call are of one kind (config 3: 8 410-8 460 reads/s
     // with two, 8 100-8 370 with three, same-box); when the call holds very long problems (poa_feed::klass: config 4's
     // 100 000-row chains) their launch occupies a slot for a second, and a third slot keeps two for everything else
