@@ -199,21 +199,35 @@ __global__ __launch_bounds__(64) void k_sg_mark(const sg_desc *__restrict__ desc
         uint32_t prefix_diff = d.q_first;
         const uint32_t start_prefix_on_node = d.t_first - sg_select(ix, first_handle >> 1);
         if (start_prefix_on_node < prefix_diff) prefix_diff -= start_prefix_on_node; else prefix_diff = 0;
-        if (prefix_diff > 0) sg_extend(ix, first_handle, prefix_diff, true, best, stamp, q0, q1, touched, level, s_cnt, &s_touched, lane);
+        uint32_t wlo = first_handle >> 5, whi = last_handle >> 5;
+        // the handles a walk reached go into the set, and their budgets are cleared before the other walk starts (the two
+        // walks are independent in the reference: a handle the upstream walk reached with a large budget must still be
+        // expanded by the downstream walk -- they can only meet on cyclic or strand-mixing graphs)
+        auto harvest = [&]() {
+            __syncthreads();
+            const uint32_t nt = s_touched;
+            for (uint32_t i = (uint32_t)lane; i < nt; i += 64) {
+                const uint32_t h = sg_ld(touched + i);
+                atomicOr(bm + (h >> 5), 1u << (h & 31u));
+                best[h] = 0;
+                wlo = min(wlo, h >> 5);
+                whi = max(whi, h >> 5);
+            }
+            __syncthreads();
+            if (lane == 0) s_touched = 0;
+            __syncthreads();
+        };
+        if (prefix_diff > 0) {
+            sg_extend(ix, first_handle, prefix_diff, true, best, stamp, q0, q1, touched, level, s_cnt, &s_touched, lane);
+            harvest();
+        }
         // align.rs:593-612
         uint32_t suffix_diff = d.qlen - (d.q_last + k);
         const uint32_t end_suffix_on_node = sg_select(ix, (last_handle >> 1) + 1) - 1 - (d.te_last - 1);
         if (end_suffix_on_node > suffix_diff) suffix_diff = 0; else suffix_diff -= end_suffix_on_node;
-        if (suffix_diff > 0) sg_extend(ix, last_handle, suffix_diff, false, best, stamp, q0, q1, touched, level, s_cnt, &s_touched, lane);
-        __syncthreads();
-        const uint32_t nt = s_touched;
-        uint32_t wlo = first_handle >> 5, whi = last_handle >> 5;
-        for (uint32_t i = (uint32_t)lane; i < nt; i += 64) {
-            const uint32_t h = sg_ld(touched + i);
-            atomicOr(bm + (h >> 5), 1u << (h & 31u));
-            best[h] = 0;
-            wlo = min(wlo, h >> 5);
-            whi = max(whi, h >> 5);
+        if (suffix_diff > 0) {
+            sg_extend(ix, last_handle, suffix_diff, false, best, stamp, q0, q1, touched, level, s_cnt, &s_touched, lane);
+            harvest();
         }
         wlo = wave_min(wlo);
         whi = wave_max(whi);
