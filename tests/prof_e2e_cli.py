@@ -1,6 +1,6 @@
 """End-to-end wall clock of the product CLI on config 3 (FASTA in -> GAF files out), for DESIGN.md section 5:
     python tests/prof_e2e_cli.py [n_reads] [extra vgaligner map flags ...]
-E2E_WORKLOAD=config4 runs the merged, sorted HLA graph (19 loci) instead of DRB1-3123.
+E2E_WORKLOAD=config4 runs the merged, sorted HLA graph (19 loci) instead of DRB1-3123, config5 the 1 Mbp synthetic pangenome.
 Not the bench line: it includes reading the FASTA, the index load + upload, GAF text generation and file output."""
 import json, os, subprocess, sys, tempfile, time
 
@@ -17,6 +17,9 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
     if os.environ.get("E2E_WORKLOAD") == "config4":
         gfa = os.path.join(d, "hla19.gfa")
         p.readsim.config4_graph(os.path.join(ROOT, "tests", "golden", "data"), gfa)
+    if os.environ.get("E2E_WORKLOAD") == "config5":
+        gfa = os.path.join(d, "syn1m.gfa")
+        p.readsim.synth_pangenome(gfa, 1000000, seed=77)
     reads = p.readsim.config3_reads(gfa, n)
     fa = os.path.join(d, "reads.fa")
     p.readsim.write_fasta(reads, fa)
