@@ -58,6 +58,16 @@ std::string gaf_placeholder(const QuerySequence &q)
     return q.name + "\t" + std::to_string(q.seq.size()) + "\t*\t*\t*\t*\t*\t*\t*\t*\t*\t0\t*\n";
 }
 
+namespace {
+inline void put_u64(std::string &s, uint64_t v)
+{
+    char t[24];
+    int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) s.push_back(t[--n]);
+}
+}  // namespace
+
 std::string gaf_from_chain(const Index &ix, const QuerySequence &q, const vga_map_result *m, uint64_t read, uint64_t chain)
 {
     if (m->chain_placeholder[chain]) return gaf_placeholder(q);
@@ -65,33 +75,61 @@ std::string gaf_from_chain(const Index &ix, const QuerySequence &q, const vga_ma
     const uint64_t c0 = m->chain_anchor_off[chain], c1 = m->chain_anchor_off[chain + 1];
     const uint64_t k = ix.kmer_length;
     std::string path;
+    path.reserve((c1 - c0) * 28);
+    // node of a forward position (get_bv_rank): the anchors of a chain ascend on the target, so the node is found by
+    // walking on from the previous one; a position before it falls back to the binary search
+    const size_t n_ref = ix.node_ref.size();
+    uint64_t cur = 0;  // = rank of the last position looked up (0: none yet)
+    auto node_of = [&](uint64_t pos) -> uint64_t {
+        if (cur == 0 || ix.node_ref[cur - 1].seq_idx > pos) cur = ix.node_id_from_fwd_pos(pos);
+        else {
+            uint64_t steps = 0;
+            while (cur < n_ref && ix.node_ref[cur].seq_idx <= pos) {
+                cur++;
+                if (++steps == 64) { cur = ix.node_id_from_fwd_pos(pos); break; }
+            }
+        }
+        return cur;
+    };
     for (uint64_t t = c0; t < c1; t++) {
         const uint64_t ai = a0 + m->chain_anchor_idx[t];
         const uint64_t tb = m->target_begin[ai], te_incl = (uint64_t)m->target_end[ai] - 1;
-        const uint64_t fn = ix.node_id_from_fwd_pos(tb), ln = ix.node_id_from_fwd_pos(te_incl);
-        path += "(>" + std::to_string(fn) + ":" + std::to_string(tb - ix.get_bv_select(fn)) + ",>" + std::to_string(ln) + ":" +
-                std::to_string(te_incl - ix.get_bv_select(ln)) + "),";
+        const uint64_t fn = node_of(tb);
+        const uint64_t fo = tb - ix.get_bv_select(fn);
+        const uint64_t ln = node_of(te_incl);
+        const uint64_t lo = te_incl - ix.get_bv_select(ln);
+        path += "(>"; put_u64(path, fn); path.push_back(':'); put_u64(path, fo);
+        path += ",>"; put_u64(path, ln); path.push_back(':'); put_u64(path, lo);
+        path += "),";
     }
     const uint64_t first = a0 + m->chain_anchor_idx[c0], last = a0 + m->chain_anchor_idx[c1 - 1];
     // plen pstart pend residue block = 0; mapq = min(f64::MIN as u64, 254) = 0 (align.rs:904, chain.rs:203)
-    return q.name + "\t" + std::to_string(q.seq.size()) + "\t" + std::to_string(m->query_begin[first]) + "\t" +
-           std::to_string(m->query_begin[last] + k) + "\t+\t" + path + "\t0\t0\t0\t0\t0\t0\tta:Z:chain,n_anchors: " +
-           std::to_string(c1 - c0) + "\n";
+    std::string out;
+    out.reserve(q.name.size() + path.size() + 96);
+    out += q.name; out.push_back('\t'); put_u64(out, q.seq.size()); out.push_back('\t'); put_u64(out, m->query_begin[first]);
+    out.push_back('\t'); put_u64(out, m->query_begin[last] + k); out += "\t+\t"; out += path;
+    out += "\t0\t0\t0\t0\t0\t0\tta:Z:chain,n_anchors: "; put_u64(out, c1 - c0); out.push_back('\n');
+    return out;
 }
 
 std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a, uint64_t r)
 {
     if (!a->aligned[r]) return gaf_placeholder(q);
-    std::string path;
-    for (uint64_t t = a->path_off[r]; t < a->path_off[r + 1]; t++) {
-        Handle h = a->path_handles[t];
-        path += (is_rev(h) ? "<" : ">") + std::to_string(id_of(h));
-    }
-    const std::string len = std::to_string(q.seq.size());
+    const char *cs = a->cs + a->cs_off[r], *cg = a->cigar + a->cigar_off[r];
+    const size_t n_cs = strlen(cs), n_cg = strlen(cg);
+    std::string out;
+    out.reserve(q.name.size() + (a->path_off[r + 1] - a->path_off[r]) * 8 + n_cs + n_cg + 128);
     // align.rs:1145-1167: qstart 0, qend len, '+', residue 0, mapq 255, literal "as:i:-30"
-    return q.name + "\t" + len + "\t0\t" + len + "\t+\t" + path + "\t" + std::to_string(a->path_length[r]) + "\t" +
-           std::to_string(a->path_start[r]) + "\t" + std::to_string(a->path_end[r]) + "\t0\t" + std::to_string(a->block_length[r]) +
-           "\t255\tas:i:-30 " + (a->cs + a->cs_off[r]) + ",cg:Z:" + (a->cigar + a->cigar_off[r]) + "\n";
+    out += q.name; out.push_back('\t'); put_u64(out, q.seq.size()); out += "\t0\t"; put_u64(out, q.seq.size()); out += "\t+\t";
+    for (uint64_t t = a->path_off[r]; t < a->path_off[r + 1]; t++) {
+        const Handle h = a->path_handles[t];
+        out.push_back(is_rev(h) ? '<' : '>');
+        put_u64(out, id_of(h));
+    }
+    out.push_back('\t'); put_u64(out, a->path_length[r]); out.push_back('\t'); put_u64(out, a->path_start[r]);
+    out.push_back('\t'); put_u64(out, a->path_end[r]); out += "\t0\t"; put_u64(out, a->block_length[r]);
+    out += "\t255\tas:i:-30 "; out.append(cs, n_cs); out += ",cg:Z:"; out.append(cg, n_cg); out.push_back('\n');
+    return out;
 }
 
 // src/validate.rs:36-102.  The record is derived from the GAF record alone, as in the reference: read name, the last
