@@ -459,8 +459,7 @@ int sg_run_part(vga_ctx *ctx, sg_ws &W, sg_store &store, int k, uint64_t p0, uin
 {
     sg_part &P = store.part[k];
     P.p0 = p0; P.p1 = p1;
-    P.ready = true;
-    if (p1 <= p0) return VGA_OK;
+    if (p1 <= p0) { P.ready = true; return VGA_OK; }
     const uint64_t n = p1 - p0;
     const vga_dev_index &dix = ctx->index;
     sg_index ix = {dix.d_node_start, dix.d_edge_idx, dix.d_edges_to, dix.d_edges, dix.d_seq_fwd, (uint32_t)dix.n_nodes};
@@ -506,6 +505,7 @@ int sg_run_part(vga_ctx *ctx, sg_ws &W, sg_store &store, int k, uint64_t p0, uin
     SG_CHECK(hipStreamSynchronize(st));
     P.d_ntab = B.d_ntab.p; P.d_preds = B.d_preds.p; P.d_sinks = B.d_sinks.p; P.d_seq = B.d_seq.p;
     P.h_handles = B.h_handles.p; P.h_first_row = B.h_first_row.p;
+    P.ready = true;
     return VGA_OK;
 }
 
