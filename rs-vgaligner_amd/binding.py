@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VGA_LIB") or os.path.join(_HERE, "libvga_hip.so")  # VGA_LIB: e.g. the variants build (csrc/Makefile)
+LIB_PATH = os.environ.get("VGA_LIB") or os.path.join(_HERE, "libvga_hip.so")  # VGA_LIB: another build of the library (same-box A/B runs)
 
 VGA_OK = 0
 ERR_NAMES = {-1: "VGA_ERR_ARG", -2: "VGA_ERR_HIP", -3: "VGA_ERR_NOMEM", -4: "VGA_ERR_UNSUPPORTED",

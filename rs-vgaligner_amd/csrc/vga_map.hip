@@ -4,7 +4,7 @@
 //                                 filter and id assignment of anchors_for_query
 //                                 (src/io.rs:41-56, src/index.rs:309-382, src/chain.rs:134-173)
 //   K2  k_anchor_sort             the stable sort of chain_anchors (src/chain.rs:386-389)
-//   K3  k_chain                   the windowed DP (src/chain.rs:398-450, score_anchor 274-368) and
+//   K3  k_chain4                  the windowed DP (src/chain.rs:398-450, score_anchor 274-368) and
 //                                 the backtracking into chains (src/chain.rs:455-558)
 //
 // All of it is integer / f64 latency-bound work on a few hundred KB per read; it is laid out so
@@ -215,130 +215,10 @@ __global__ __launch_bounds__(256) void k_anchor_gather_seg(const uint64_t *__res
     }
 }
 
-#ifdef VGA_VARIANTS  // the first form of K3 (18 ds_bpermute per step), superseded by k_chain4: `make variants` builds it for cross-checks
-// ------------------------------------------------------------------------------------------ K3
-// One wavefront per read.  Lane l keeps the most recent sorted anchor j with j % 64 == l in
-// registers, so the look-back window (bandwidth <= 64) is always register-resident; each step
-// scores anchor i against the whole window at once and reduces with a 64-lane butterfly.
-// Tie rule: the reference scans j from i-1 downwards with a strict '>' (src/chain.rs:417,430), so
-// among equal proposed scores the largest j wins.
-__device__ __forceinline__ void vga_argmax_step(double &p, int &j, int d)
-{
-    double op = __shfl_xor(p, d, 64);
-    int oj = __shfl_xor(j, d, 64);
-    if (op > p || (op == p && oj > j)) { p = op; j = oj; }
-}
 
-__global__ __launch_bounds__(VGA_WAVE) void k_chain(
-    const uint64_t *__restrict__ anchor_off, const uint32_t *__restrict__ s_id, const uint32_t *__restrict__ s_qb,
-    const uint32_t *__restrict__ s_tb, const uint32_t *__restrict__ s_te, uint32_t k, uint32_t bandwidth,
-    uint64_t max_gap, uint32_t min_anchors, const double *__restrict__ gap_cost, double *__restrict__ f_out,
-    int32_t *__restrict__ pred_id_out, int32_t *pred_pos, double *__restrict__ curr_max_out,
-    uint32_t *__restrict__ chain_buf, uint32_t *__restrict__ chain_cnt, uint32_t *__restrict__ chain_words)
-{
-    const uint32_t r = blockIdx.x;
-    const uint32_t lane = threadIdx.x;
-    const uint64_t a0 = anchor_off[r];
-    const uint32_t A = (uint32_t)(anchor_off[r + 1] - a0);
-    const double kd = (double)k;
-    double curr_max = 0.0;
-
-    double f_l = 0.0;
-    uint32_t qb_l = 0, tb_l = 0, te_l = 0;
-    int j_l = -1;
-
-    for (uint32_t i = 0; i < A; i++) {
-        const uint32_t qbi = s_qb[a0 + i], tbi = s_tb[a0 + i], tei = s_te[a0 + i];  // wave-uniform
-        double p = -1.7976931348623157e308;  // -f64::MAX
-        int j = -1;
-        if (i > 0) {
-            const int min_j = (bandwidth > i) ? 0 : (int)(i - bandwidth);  // src/chain.rs:404-407
-            if (j_l >= min_j) {
-                // score_anchor(a = j_l, b = i), src/chain.rs:274-368; bit 31 = orientation, see k_chain4
-                if ((tb_l >> 31) == (tei >> 31) && (te_l >> 31) == (tei >> 31) && (tbi >> 31) == (tei >> 31) && !(qb_l >= qbi || te_l >= tei)) {
-                    const uint64_t ql = (uint64_t)(qbi - qb_l);
-                    const uint64_t tbd = tbi > tb_l ? (uint64_t)(tbi - tb_l) : (uint64_t)(tb_l - tbi);
-                    const uint64_t ted = (uint64_t)(tei - te_l);
-                    const uint64_t tl = tbd < ted ? tbd : ted;
-                    const uint64_t g = ql > tl ? ql - tl : tl - ql;
-                    if (g <= max_gap) {
-                        const double gc = gap_cost[g];
-                        uint64_t ml = ql < tl ? ql : tl;
-                        if ((uint64_t)k < ml) ml = k;
-                        double s = f_l + (double)ml;
-                        s = s - gc;
-                        s = s * 1000.0;
-                        s = round(s);
-                        s = s / 1000.0;
-                        s = s + 0.0;
-                        p = s;
-                        j = j_l;
-                    }
-                }
-            }
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) vga_argmax_step(p, j, d);
-        }
-        double fi = kd;  // src/chain.rs:163: initial f(i) = k
-        int pj = -1;
-        if (p > fi) { fi = p; pj = j; }
-        if (p > curr_max) curr_max = p;
-        if (lane == (i & 63u)) { f_l = fi; qb_l = qbi; tb_l = tbi; te_l = tei; j_l = (int)i; }
-        if (lane == 0) {
-            f_out[a0 + i] = fi;
-            pred_pos[a0 + i] = pj;
-            pred_id_out[a0 + i] = pj >= 0 ? (int32_t)s_id[a0 + pj] : -1;
-        }
-    }
-    if (lane == 0) curr_max_out[r] = curr_max;
-    __threadfence_block();
-
-    // ---- backtracking, src/chain.rs:455-558.  Chains are emitted in discovery order (highest sorted
-    // index first), members in walk order (descending); the host reverses each chain.
-    uint32_t *buf = chain_buf + 3 * a0 + 2 * (uint64_t)r;
-    volatile int32_t *vpred = pred_pos + a0;
-    const double *fr = f_out + a0;
-    uint32_t nch = 0, wpos = 0;
-    for (int top = (int)A; top > 0; top -= 64) {
-        const int i = top - 1 - (int)lane;
-        bool cand = false;
-        if (i >= 0) cand = vpred[i] >= 0 && fr[i] == curr_max;
-        uint64_t mask = __ballot(cand);
-        while (mask) {
-            const int l = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            int cur = top - 1 - l;
-            if (vpred[cur] < 0) continue;  // consumed by an earlier chain (src/chain.rs:469,478)
-            const uint32_t hdr = wpos++;
-            uint32_t len = 0;
-            int pnext;
-            while ((pnext = vpred[cur]) >= 0) {
-                if (lane == 0) { vpred[cur] = -1; buf[wpos] = (uint32_t)cur; }
-                __threadfence_block();
-                wpos++;
-                len++;
-                cur = pnext;
-            }
-            if (lane == 0) buf[wpos] = (uint32_t)cur;
-            wpos++;
-            len++;
-            if (len >= min_anchors) {
-                if (lane == 0) buf[hdr] = len;
-                nch++;
-            } else {
-                wpos = hdr;
-            }
-        }
-    }
-    if (lane == 0) { chain_cnt[r] = nch; chain_words[r] = wpos; }
-}
-
-#endif  // VGA_VARIANTS
-
-// K3, current form.  Same recurrence, window and tie rule as k_chain (kept below the name k_chain for cross-checks,
-// VGA_MAP_CHAIN=old); what changes is the latency of one step of the serial chain, ~4 300 cycles there:
-//   * the argmax over the window is a DPP max-reduction of the f64 scores (18 VALU instructions, result in lane 63)
-//     instead of a 6-stage butterfly of 18 ds_bpermute; the winning j follows from the ballot of the lanes that hold
+// K3.  What sets the latency of one step of the serial chain:
+//   * the argmax over the window is a DPP max-reduction of the f64 scores (18 VALU instructions, result in lane 63;
+//     round 1's first form used a 6-stage butterfly of 18 ds_bpermute); the winning j follows from the ballot of the lanes that hold
 //     the maximum: lane l keeps the most recent anchor j = l (mod 64), so the largest j is the set lane cyclically
 //     nearest below (i - 1) & 63 -- a rotate and a count-leading-zeros on the scalar unit;
 //   * the gap-cost table sits in LDS (shared by the four reads of a workgroup) instead of a per-lane gather from HBM;
@@ -462,7 +342,7 @@ __global__ __launch_bounds__(256) void k_chain4(
     if (lane == 0) curr_max_out[r] = curr_max;
     __threadfence_block();
 
-    // ---- backtracking, src/chain.rs:455-558 (as in k_chain)
+    // ---- backtracking, src/chain.rs:455-558
     uint32_t *buf = chain_buf + 3 * a0 + 2 * (uint64_t)r;
     volatile int32_t *vpred = pred_pos + a0;
     const double *fr = f_out + a0;
@@ -714,17 +594,10 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
     // ---- K3: chain DP + backtracking
     int t4 = vga_timer_begin(ctx, "chain_dp", 16 * total + 12 * total);
     {
-        const char *cv = getenv("VGA_MAP_CHAIN");  // "old": the butterfly kernel (cross-check)
         const size_t gap_bytes = (size_t)(params->max_gap + 1) * sizeof(double);
 #define CHAIN_ARGS ws.anchor_off.p, perm, ws.s_qb.p, ws.s_tb.p, ws.s_te.p, ix.k, params->bandwidth, params->max_gap,           \
                    params->chain_min_n_anchors, ws.gap_cost.p, ws.f.p, ws.pred_id.p, ws.pred_pos.p, ws.curr_max.p,         \
                    ws.chain_buf.p, ws.chain_cnt.p, ws.chain_words.p
-#ifdef VGA_VARIANTS
-        if (cv && strstr(cv, "old"))
-            hipLaunchKernelGGL(k_chain, dim3((unsigned)R), dim3(VGA_WAVE), 0, st, CHAIN_ARGS);
-        else
-#endif
-        (void)cv;
         if (gap_bytes <= 16 * 1024)  // (8 KB at the default max_gap; bigger tables stay in HBM)
             hipLaunchKernelGGL(k_chain4<true>, dim3((unsigned)((R + 3) / 4)), dim3(256), gap_bytes, st, (uint32_t)R, CHAIN_ARGS);
         else

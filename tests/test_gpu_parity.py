@@ -362,11 +362,9 @@ _long_ok = pytest.mark.skipif(any(k in os.environ.get("VGA_POA_KERNEL", "") for 
 
 
 @_long_ok
-def test_poa_mixed_problem_sizes_and_unbanded_long_query(oracle, ctx, drb1, monkeypatch):
+def test_poa_mixed_problem_sizes_and_unbanded_long_query(oracle, ctx, drb1):
     """random problems of very different sizes in one batch, and an unbanded 33 kbp query against a tiny graph (H falls below
-    -30 000 along the first row).  With the variants build (VGA_LIB=.../libvga_hip_variants.so) VGA_POA_H16=1 selects round
-    1's 16-bit row state here: a problem whose scores come near the int16 range is re-run with 32-bit words."""
-    monkeypatch.setenv("VGA_POA_H16", "1")
+    -30 000 along the first row)."""
     rng = random.Random(4321)
     problems = [_rand_problem(rng, rng.randint(1, 40), 6) for _ in range(60)]
     problems += [_rand_problem(rng, rng.randint(20, 120), 12, qlen_scale=s) for s in (0.3, 1.0) for _ in range(8)]
@@ -427,23 +425,6 @@ def test_poa_query_longer_than_a_pool_chunk_of_scratch(oracle, ctx):
     q = "".join(rng.choice("ACGT") for _ in range(140000))
     bubble = (["ACGT", "TT", "GA", "CCAT"], [(0, 1), (0, 2), (1, 3), (2, 3)], q[:70000] + "ACGTTTCCAT" + q[70000:])
     _check_poa(oracle, ctx, [(["ACGT", "TTGA"], [(0, 1)], q), bubble])
-
-
-def test_poa_one_wave_per_problem_kernel(oracle, ctx, drb1, monkeypatch):
-    """VGA_POA_W1=1: k_poa_dp_w1 (vga_poa_w1.hpp) -- one wave per problem, the row state in 144 hand-managed vector registers
-    addressed through gfx9's VGPR index mode.  Parity-green but 2.3x slower than k_poa_dp_t4 on config 3 (a single wave per
-    problem is latency-bound at two waves per SIMD), hence opt-in.  Problems it hands back
-    (POA_ST_WIDE: a band beyond 6 144 columns, non-ACGT query bases) are re-run by k_poa_dp_t4."""
-    monkeypatch.setenv("VGA_POA_W1", "1")
-    rng = random.Random(77)
-    problems = [_rand_problem(rng, rng.randint(1, 40), 6) for _ in range(40)] + [_rand_problem(rng, 60, 60) for _ in range(3)]
-    problems.append((["ACGT", "TTGA"], [(0, 1)], "".join(rng.choice("ACGT") for _ in range(9000))))  # 9 001 columns: handed back
-    problems.append((["AC", "GT", "NN"], [(0, 1), (1, 2)], "ACNGTNN"))
-    _check_poa(oracle, ctx, problems)
-    _, ix = drb1
-    upload_oracle_index(ctx, ix)
-    _check_align(oracle, ctx, ix, pkg().readsim.simulate_reads(DRB1, 4, 2500, 0.03, 0.03, 0.04, seed=13))
-    _check_align(oracle, ctx, ix, pkg().readsim.config3_reads(DRB1, 2))
 
 
 def _fallback_problems(rng):
