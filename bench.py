@@ -42,6 +42,8 @@ def main():
                     help="config3 (default, the headline line): DRB1-3123; config4: the 19 merged, sorted HLA-zoo loci; config5: 1 Mbp synthetic "
                          "pangenome (same read model); config2: DRB1-3123, 150 bp reads with 1 %% substitutions, map-only "
                          "(anchor + chain kernels; use --reads 1000 for BASELINE's size).  Extra measurements, not the driver's line")
+    ap.add_argument("--remain-rule", type=int, choices=[0, 1], default=None,
+                    help="vga_poa_params.remain_rule: 0 longest path, 1 first out-edge (default: the library's default)")
     args = ap.parse_args()
 
     import torch
@@ -117,7 +119,11 @@ def main():
         torch.cuda.synchronize()
 
     last = None
-    step = batch.map_raw if map_only else batch.map_align_raw
+    poa_params = pkg.default_poa_params()
+    if args.remain_rule is None:
+        args.remain_rule = int(poa_params.remain_rule)
+    poa_params.remain_rule = args.remain_rule
+    step = batch.map_raw if map_only else (lambda: batch.map_align_raw(poa_params=poa_params))
     for _ in range(args.warmup):
         last = step()
     barrier()
@@ -176,33 +182,54 @@ def main():
     # launch intervals from the same hipEvents): achieved = algorithmic bytes of all launches / busy time.
     avg_ms = d["ms"] / max(d["launches"], 1)
     busy_per_launch = d["busy_ms"] / max(d["launches"], 1)
-    bytes_per_launch = d["bytes"] / max(d["launches"], 1)
+    launches_per_step = max(d["launches"] / args.steps, 1)
+    impl_bytes_per_launch = d["bytes"] / max(d["launches"], 1)  # the library's own byte model of the kernel
+    formula = None
+    operands = None
+    if dom == "poa_band_dp" and last.get("poa_cells"):
+        # SURVEY.md section 8(d):  B_poa = N + L + 4 C + 4 (N_path + L) + P  per step, every operand from this run's counters
+        # (N graph bases = DP rows, L query bases, C band cells, N_path graph bases on the alignment paths, P CIGAR bytes)
+        operands = {"N": last["poa_rows"], "L": sum(len(s) for s in seqs), "C": last["poa_cells"], "N_path": last["path_bases"],
+                    "P": last["cigar_bytes"], "C_v": last["poa_value_cells"]}
+        formula = "N + L + 4*C + 4*(N_path + L) + P   (SURVEY.md 8d, per step; / launches_per_step = per launch)"
+        bytes_per_step = operands["N"] + operands["L"] + 4 * operands["C"] + 4 * (operands["N_path"] + operands["L"]) + operands["P"]
+        bytes_per_launch = bytes_per_step / launches_per_step
+    else:
+        bytes_per_launch = impl_bytes_per_launch
     achieved = bytes_per_launch / (busy_per_launch * 1e-3) / 1e9 if busy_per_launch > 0 else 0.0
     traffic = None
+    traffic_src = None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
             tj = json.load(open(tp))
             if (tj.get("kernel") == dom and tj.get("reads") == args.reads and tj.get("read_len") == args.read_len
-                    and args.workload == "config3"):
+                    and args.workload == "config3" and tj.get("remain_rule", 0) == args.remain_rule):
                 # measured with rocprofv3 PMC passes (profiles/traffic.json), per step; per launch = / launches per step
-                traffic = int(tj["hbm_bytes_per_step"] / max(d["launches"] / args.steps, 1))
+                traffic = int(tj["hbm_bytes_per_step"] / launches_per_step)
+                traffic_src = "committed profile (profiles/traffic.json: %s), not measured in this run" % tj.get("tag", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "avg_launch_ms": round(avg_ms, 3),
-                "busy_ms_per_launch": round(busy_per_launch, 3), "concurrency": round(d["ms"] / d["busy_ms"], 3) if d["busy_ms"] > 0 else None,
-                "launches": d["launches"], "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                "frac_8d": round(achieved / HBM_PEAK_GBS, 5) if formula else None,
+                "algorithmic_bytes_per_launch": int(bytes_per_launch), "formula": formula, "operands_per_step": operands,
+                "launches_per_step": launches_per_step, "busy_ms_per_launch": round(busy_per_launch, 3),
+                "timing": "live: hipEvents on the library's launch streams; busy = union of the launch intervals (launches overlap)",
+                "avg_launch_ms": round(avg_ms, 3), "concurrency": round(d["ms"] / d["busy_ms"], 3) if d["busy_ms"] > 0 else None,
+                "launches": d["launches"],
                 "peak_measured_copy": copy_gbs, "frac_of_measured_copy": round(achieved / copy_gbs, 5) if copy_gbs else None}
-    # the POA kernel's bytes split: compulsory = graph bases + query + one direction byte per band cell
-    # (+ the traceback's reads); value rows = what the node-end rows cost in this implementation (written once, read back once)
-    if dom == "poa_band_dp" and last.get("poa_cells"):
-        comp = (last["poa_rows"] + last["n_reads"] * args.read_len + last["poa_cells"]) * args.steps
-        tot = d["bytes"]
-        roofline["bytes_split"] = {"compulsory_per_launch": int(comp / max(d["launches"], 1)),
-                                   "value_rows_per_launch": int(max(tot - comp, 0) / max(d["launches"], 1)),
-                                   "achieved_compulsory_only": round(comp / (d["busy_ms"] * 1e-3) / 1e9, 2) if d["busy_ms"] > 0 else None,
-                                   "frac_compulsory_only": round(comp / (d["busy_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if d["busy_ms"] > 0 else None}
+    if operands:
+        # the same kernel priced on this implementation's own traffic model (1 direction byte per cell instead of 8d's int32,
+        # 6-byte value rows written once and read back once) and on the compulsory part of it alone
+        comp = operands["N"] + operands["L"] + operands["C"]
+        impl_gbs = impl_bytes_per_launch / (busy_per_launch * 1e-3) / 1e9 if busy_per_launch > 0 else 0.0
+        comp_gbs = comp / launches_per_step / (busy_per_launch * 1e-3) / 1e9 if busy_per_launch > 0 else 0.0
+        roofline["frac_impl"] = round(impl_gbs / HBM_PEAK_GBS, 5)
+        roofline["impl"] = {"formula": "N + L + C + 12*C_v + 6*(alignment columns)", "bytes_per_launch": int(impl_bytes_per_launch),
+                            "achieved": round(impl_gbs, 2), "frac": round(impl_gbs / HBM_PEAK_GBS, 5)}
+        roofline["compulsory"] = {"formula": "N + L + C", "bytes_per_launch": int(comp / launches_per_step), "achieved": round(comp_gbs, 2),
+                                  "frac": round(comp_gbs / HBM_PEAK_GBS, 5)}
         # the ceiling the kernel is actually under: instruction issue.  Counts per band cell come from the committed PMC run
         # (profiles/instr.json: SQ_INSTS_VALU / SQ_INSTS_SALU of one bench step), the sustainable rate from the microbenchmark
         # (profiles/r02_valu_issue_microbench.txt: ~0.58 T wave64 VALU instructions/s chip-wide for this instruction mix)
@@ -210,12 +237,13 @@ def main():
         if os.path.exists(ip) and args.workload == "config3":
             try:
                 ij = json.load(open(ip))
-                cells = last["poa_cells"] * args.steps
-                valu = ij["valu_wave_instr_per_64_cells"] * cells / 64.0
-                rate = valu / (d["busy_ms"] * 1e-3)
-                roofline["valu"] = {"bound": "valu_issue", "achieved": round(rate / 1e9, 1), "peak": ij["peak_Gwaveinst_per_s"], "unit": "G wave64 instr/s",
-                                    "frac": round(rate / 1e9 / ij["peak_Gwaveinst_per_s"], 4), "valu_per_64_cells": ij["valu_wave_instr_per_64_cells"],
-                                    "salu_per_64_cells": ij.get("salu_wave_instr_per_64_cells"), "source": ij.get("source")}
+                if ij.get("remain_rule", 0) == args.remain_rule:
+                    valu = ij["valu_wave_instr_per_64_cells"] * operands["C"] / 64.0
+                    rate = valu / (d["busy_ms"] / args.steps * 1e-3)
+                    roofline["valu"] = {"bound": "valu_issue", "achieved": round(rate / 1e9, 1), "peak": ij["peak_Gwaveinst_per_s"], "unit": "G wave64 instr/s",
+                                        "frac": round(rate / 1e9 / ij["peak_Gwaveinst_per_s"], 4), "valu_per_64_cells": ij["valu_wave_instr_per_64_cells"],
+                                        "salu_per_64_cells": ij.get("salu_wave_instr_per_64_cells"),
+                                        "source": "committed profile (profiles/instr.json), instruction counts not measured in this run; cells and busy time are live. " + str(ij.get("source"))}
             except Exception:
                 pass
 
@@ -275,7 +303,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%s, k=11, %d x %d bp %s reads per GPU%s"
                                % (wl_name, args.reads, args.read_len, "1 %-substitution" if map_only else "ONT-profile", "" if map_only else ", --also-align"),
-                   "reads_per_gpu": args.reads, "read_len": args.read_len, "sharding": "reads, replicated index, no collective"},
+                   "reads_per_gpu": args.reads, "read_len": args.read_len, "sharding": "reads, replicated index, no collective",
+                   "poa_remain_rule": ["longest-path", "first-out-edge"][args.remain_rule]},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "cpu_baseline_faithful": cpu_faithful,

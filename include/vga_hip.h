@@ -148,8 +148,18 @@ typedef struct {
     int32_t gap_open2; /* 24 */
     int32_t gap_ext2;  /* 1  */
     int32_t wb;        /* 10, adaptive band: w = wb + floor(wf * qlen); wb < 0 disables banding */
+    int32_t remain_rule; /* VGA_REMAIN_*: which path the diagonal term  qlen - remain[row]  of the adaptive band follows
+                          * (ABI 4; it occupies what was padding before `wf`, so sizes and offsets are unchanged) */
     double wf;         /* 0.01 */
 } vga_poa_params;
+/* remain[row] = graph bases after the row on one path to the sink.  abPOA's source is not in the reference tree, so which
+ * path it takes is unverified; both readings are implemented and parity-tested (oracle/og_poa.c):
+ *   LONGEST_PATH   the longest path to the sink (rounds 1-2 of this library);
+ *   FIRST_OUT_EDGE the path that follows the heaviest out-edge, the first on a tie -- abPOA's abpoa_BFS_set_node_remain
+ *                  as remembered; with the unit weights of a graph built from node strings + an edge list that is the
+ *                  first out-edge in edge-list order. */
+#define VGA_REMAIN_LONGEST_PATH 0
+#define VGA_REMAIN_FIRST_OUT_EDGE 1
 void vga_poa_default_params(vga_poa_params *p);
 
 /* The fields of ab_poa's AbpoaAlignmentResult that the reference consumes

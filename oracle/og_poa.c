@@ -13,8 +13,19 @@
  *   - adaptive band per row r:  w = b + floor(f*qlen), b=10, f=0.01,
  *       beg = max(0,    min(max_pos_left[r],  qlen - remain[r]) - w)
  *       end = min(qlen, max(max_pos_right[r], qlen - remain[r]) + w)
- *     remain[r] = graph bases after r on the longest path to the sink; after a row is filled the
- *     leftmost/rightmost column of its maximum (+1) is pushed to every successor row.
+ *     remain[r] = graph bases after r on ONE path to the sink -- which one is an OPEN CHOICE with first-order effects
+ *     (it moves the band, hence results, and it sets the band's width, hence cost), exposed as
+ *     og_poa_params.remain_rule:
+ *       OG_REMAIN_LONGEST_PATH   (0) the longest path (rounds 1-2 of this repository: the reading of the paper's
+ *                                    "number of remaining bases");
+ *       OG_REMAIN_FIRST_OUT_EDGE (1) the path that follows, from every base, its heaviest out-edge, the first one on a
+ *                                    tie -- what abPOA's public source is remembered to do (abpoa_graph.c,
+ *                                    abpoa_BFS_set_node_remain: "max weight out_id", strict >); a graph that was only
+ *                                    built from node strings and an edge list has unit weights everywhere, so this is
+ *                                    the FIRST out-edge in edge-list order (for the virtual source: the first node
+ *                                    without a predecessor).  Neither abPOA nor the rs-abpoa wrapper is in the
+ *                                    reference tree, so which of the two the reference computes is UNVERIFIED.
+ *     After a row is filled the leftmost/rightmost column of its maximum (+1) is pushed to every successor row.
  * What abPOA leaves to its SIMD implementation (band rounding to vector width, tie order in the
  * traceback) is fixed here as this repository's specification:
  *   - H = max(M, E1, E2, F1, F2); ties resolve in that order; among predecessors the first in
@@ -48,6 +59,7 @@ void og_poa_default_params(og_poa_params *p)
     p->gap_ext2 = 1;
     p->wb = 10;
     p->wf = 0.01;
+    p->remain_rule = OG_REMAIN_LONGEST_PATH;
 }
 
 void og_poa_result_free(og_poa_result *r)
@@ -135,12 +147,19 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
     free(in_fill);
     free(out_fill);
 
-    /* remain[r]: graph bases after r on the longest path to the sink */
+    /* remain[r]: graph bases after r on the path to the sink that remain_rule names (see the header) */
+    if (P->remain_rule != OG_REMAIN_LONGEST_PATH && P->remain_rule != OG_REMAIN_FIRST_OUT_EDGE) {
+        free(first_row); free(last_row); free(row_base); free(row_node);
+        free(in_off); free(out_off); free(in_adj); free(out_adj);
+        return OG_ERR_ARG;
+    }
+    const int first_edge = P->remain_rule == OG_REMAIN_FIRST_OUT_EDGE;
     int64_t *remain = (int64_t *)calloc(N + 2, sizeof(int64_t));
     for (size_t v = n_nodes; v-- > 0;) {
         int64_t rl = 0;
         for (size_t t = out_off[v]; t < out_off[v + 1]; t++) {
             int64_t c = 1 + remain[first_row[out_adj[t]]];
+            if (first_edge) { rl = c; break; }
             if (c > rl) rl = c;
         }
         remain[last_row[v]] = rl;
@@ -149,6 +168,7 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
     for (size_t v = 0; v < n_nodes; v++)
         if (in_off[v + 1] == in_off[v]) {
             int64_t c = 1 + remain[first_row[v]];
+            if (first_edge) { remain[0] = c; break; }
             if (c > remain[0]) remain[0] = c;
         }
 

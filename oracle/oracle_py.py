@@ -106,6 +106,7 @@ class PoaParams(C.Structure):
         ("gap_ext2", C.c_int32),
         ("wb", C.c_int32),
         ("wf", C.c_double),
+        ("remain_rule", C.c_int32),  # 0 longest path, 1 first out-edge (vga_oracle.h: OG_REMAIN_*)
     ]
 
 

@@ -214,7 +214,12 @@ typedef struct {
     int32_t gap_ext2;   /* 1 */
     int32_t wb;         /* 10; <0 disables banding */
     double wf;          /* 0.01 */
+    int32_t remain_rule; /* which path `remain` (the diagonal term of the adaptive band) follows: OG_REMAIN_* */
 } og_poa_params;
+#define OG_REMAIN_LONGEST_PATH 0   /* graph bases after the row on the LONGEST path to the sink */
+#define OG_REMAIN_FIRST_OUT_EDGE 1 /* ... on the path that always takes the heaviest out-edge, first one on a tie -- with the
+                                      unit edge weights of a graph that was only ever built from node strings and an edge
+                                      list: the FIRST out-edge in edge-list order */
 void og_poa_default_params(og_poa_params *p);
 
 typedef struct {

@@ -59,7 +59,7 @@ class MapParams(C.Structure):
 
 class PoaParams(C.Structure):
     _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("gap_open1", C.c_int32), ("gap_ext1", C.c_int32),
-                ("gap_open2", C.c_int32), ("gap_ext2", C.c_int32), ("wb", C.c_int32), ("wf", C.c_double)]
+                ("gap_open2", C.c_int32), ("gap_ext2", C.c_int32), ("wb", C.c_int32), ("remain_rule", C.c_int32), ("wf", C.c_double)]
 
 
 _P = C.POINTER

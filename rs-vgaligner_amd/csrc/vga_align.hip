@@ -358,7 +358,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         // the first launch takes 2 048 problems (poa_run, arena mode); small calls are prepared in one go
         uint64_t split = n > 3072 ? 2048 : n;
         if (const char *e = getenv("VGA_SG_SPLIT")) { const long v = atol(e); split = v <= 0 ? n : std::min<uint64_t>(n, (uint64_t)v); }  // (0: one part)
-        const int rc = sg_prepare(ctx, descs.data(), q_src.data(), n, split, b->d_reads, store);
+        const int rc = sg_prepare(ctx, descs.data(), q_src.data(), n, split, b->d_reads, params->remain_rule, store);
         if (rc != VGA_OK) return rc;
         sub_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
         feed.dev = &store;

@@ -15,7 +15,7 @@
 
 #include "../../include/vga_hip.h"
 
-#define VGA_ABI_VERSION 3
+#define VGA_ABI_VERSION 4
 
 struct vga_dev_index {
     uint32_t k = 0;

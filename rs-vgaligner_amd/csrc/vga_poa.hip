@@ -80,8 +80,9 @@ struct poa_prep {
 };
 
 // Node-level graph description: first rows, predecessor rows in edge-list order, remain of the last base of each
-// node (longest-path DP over the nodes), sink predecessors.  Mirrors the row construction of oracle/og_poa.c.
-void poa_prepare(const poa_view &v, poa_prep &g)
+// node (over the nodes, last first: the longest path, or with first_edge the path through the first out-edge in
+// edge-list order -- vga_poa_params.remain_rule), sink predecessors.  Mirrors the row construction of oracle/og_poa.c.
+void poa_prepare(const poa_view &v, poa_prep &g, bool first_edge)
 {
     g.ok = false;
     const uint64_t nv = v.n_nodes;
@@ -121,11 +122,15 @@ void poa_prepare(const poa_view &v, poa_prep &g)
     std::vector<int32_t> remain_last(nv, 0), remain_first(nv, 0);
     for (uint64_t i = nv; i-- > 0;) {
         int32_t rl = 0;
-        for (uint32_t t = out_off[i]; t < out_off[i + 1]; t++) rl = std::max(rl, 1 + remain_first[out_adj[t]]);
+        for (uint32_t t = out_off[i]; t < out_off[i + 1]; t++) {
+            rl = std::max(rl, 1 + remain_first[out_adj[t]]);
+            if (first_edge) break;
+        }
         remain_last[i] = rl;
         remain_first[i] = rl + (int32_t)(last_row[i] - g.first_row[i]);
     }
     int32_t longest = 0;
+    bool have_src = false;
     g.ntab.clear();
     g.preds.clear();
     g.sinks.clear();
@@ -136,7 +141,8 @@ void poa_prepare(const poa_view &v, poa_prep &g)
         const uint32_t pstart = (uint32_t)g.preds.size();
         if (deg == 0) {
             g.preds.push_back(0);
-            longest = std::max(longest, 1 + remain_first[i]);
+            if (!(first_edge && have_src)) longest = std::max(longest, 1 + remain_first[i]);
+            have_src = true;
         } else {
             for (uint32_t t = in_off[i]; t < in_off[i + 1]; t++) g.preds.push_back(last_row[in_adj[t]]);
         }
@@ -150,7 +156,7 @@ void poa_prepare(const poa_view &v, poa_prep &g)
         if (is_sink) g.sinks.push_back(last_row[i]);
     }
     g.longest = longest;
-    g.ntab[0] = make_uint4(0u, 1u, (uint32_t)longest, 0u);  // the virtual source: row 0, remain = longest path
+    g.ntab[0] = make_uint4(0u, 1u, (uint32_t)longest, 0u);  // the virtual source: row 0, remain over the source nodes
     g.n_ntab = (uint32_t)g.ntab.size(); g.n_preds = (uint32_t)g.preds.size(); g.n_sinks = (uint32_t)g.sinks.size();
     g.first_row_p = g.first_row.data();
     g.ok = true;
@@ -231,6 +237,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         params->gap_ext1 < 0 || params->gap_ext2 < 0 || params->gap_open1 + params->gap_ext1 > 255 ||
         params->gap_open2 + params->gap_ext2 > 255)
         return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "gap penalties: open + extend must be in 0..255 (one byte per gap state)");
+    if (params->remain_rule != VGA_REMAIN_LONGEST_PATH && params->remain_rule != VGA_REMAIN_FIRST_OUT_EDGE)
+        return vga_set_error(ctx, VGA_ERR_ARG, "vga_poa_params.remain_rule %d: not one of VGA_REMAIN_*", params->remain_rule);
+    if (feed.dev && feed.dev->remain_rule != params->remain_rule)
+        return vga_set_error(ctx, VGA_ERR_ARG, "the device subgraph store was built for another remain_rule");
     if (!feed.keep_timers) vga_timers_reset(ctx);
     if (n == 0) return VGA_OK;
     uint32_t max_q = 0;
@@ -310,7 +320,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 g.n_ntab = sm.n_nodes + 1; g.n_preds = sm.n_preds; g.n_sinks = sm.n_sinks;
                 g.first_row_p = feed.dev->of(p).h_first_row + feed.dev->off[p].node0;
             } else
-                poa_prepare(views[p], G[p]);
+                poa_prepare(views[p], G[p], params->remain_rule == VGA_REMAIN_FIRST_OUT_EDGE);
             // footprint in the pool: a direction byte per cell plus the value-row ring
             if (G[p].ok) {
                 estw[p] = est_width(p);

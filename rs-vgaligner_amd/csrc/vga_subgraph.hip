@@ -276,7 +276,7 @@ __device__ inline char sg_complement(char c)
 // ---- kernel 2: handles, first rows, bases, predecessor rows, sinks, node table
 __global__ __launch_bounds__(64) void k_sg_emit(uint32_t n, sg_index ix, uint32_t words, uint32_t nh, const uint32_t *bitmaps, uint32_t *scratch,
                                                 sg_sum *sums, const sg_off *__restrict__ offs, uint32_t *handles, uint32_t *first_row, uint4 *ntab,
-                                                uint32_t *preds, uint32_t *sinks, char *seq)
+                                                uint32_t *preds, uint32_t *sinks, char *seq, int first_edge)
 {
     const int lane = threadIdx.x;
     uint32_t *wb_rank = scratch + (uint64_t)blockIdx.x * 5ull * nh, *wb_row = wb_rank + words, *wb_pred = wb_row + words, *wb_sink = wb_pred + words;
@@ -377,10 +377,11 @@ __global__ __launch_bounds__(64) void k_sg_emit(uint32_t n, sg_index ix, uint32_
         }
         life = wave_max(life);
         __syncthreads();
-        // -- D: remain of the last base of every node = longest path over its successors, last node first.  64 nodes at a
+        // -- D: remain of the last base of every node, last node first: the longest path over its successors, or
+        // (first_edge, VGA_REMAIN_FIRST_OUT_EDGE) the path through its first successor in edge-list order.  64 nodes at a
         // time: successors above the group are final; inside the group a lane only depends on lower lanes, so 64 broadcast
         // steps settle it
-        uint32_t longest = 0;
+        uint32_t longest = 0, first_src = 0xFFFFFFFFu;
         for (uint32_t g0 = 0; g0 < n_sub; g0 += 64) {
             const uint32_t top = n_sub - 1 - g0;
             const bool valid = (uint32_t)lane <= top;
@@ -390,8 +391,11 @@ __global__ __launch_bounds__(64) void k_sg_emit(uint32_t n, sg_index ix, uint32_
             if (valid) {
                 const uint32_t h = sg_ld(hd + i);
                 len = sg_len(ix, h);
+                bool taken = false;
                 sg_for_nb(ix, h, false, [&](uint32_t y) {
                     if (!(y > h && sg_member(bm, nh, y))) return;
+                    if (first_edge && taken) return;
+                    taken = true;
                     const uint32_t j = rank_of(y);
                     if (j > top) { const uint32_t c = 1u + sg_ld(rf + j); val = c > val ? c : val; }
                     else mask |= 1ull << (top - j);
@@ -406,11 +410,19 @@ __global__ __launch_bounds__(64) void k_sg_emit(uint32_t n, sg_index ix, uint32_
                 uint32_t *z = (uint32_t *)(nt + 1 + i);
                 const uint32_t y = sg_ld(z + 1), wv = sg_ld(z + 3), zf = sg_ld(z + 2);
                 z[2] = zf | val;
-                if ((y >> 24) == 1u && wv == 0u) { const uint32_t c = 1u + val + len - 1; longest = c > longest ? c : longest; }  // a node without predecessor
+                if ((y >> 24) == 1u && wv == 0u) {  // a node without predecessor
+                    const uint32_t c = 1u + val + len - 1;
+                    if (first_edge) { if (i < first_src) { first_src = i; longest = c; } }  // (the source's first out-edge: the first such node)
+                    else longest = c > longest ? c : longest;
+                }
             }
             __syncthreads();
         }
-        longest = wave_max(longest);
+        if (first_edge) {
+            const uint32_t fs = wave_min(first_src);
+            longest = wave_max(first_src == fs && fs != 0xFFFFFFFFu ? longest : 0u);
+        } else
+            longest = wave_max(longest);
         if (lane == 0) {
             nt[0] = make_uint4(0u, 1u, longest, 0u);  // the virtual source: row 0, remain = longest path
             sums[p].longest = longest;
@@ -494,7 +506,8 @@ int sg_run_part(vga_ctx *ctx, sg_ws &W, sg_store &store, int k, uint64_t p0, uin
     SG_CHECK(hipMemcpyAsync(W.d_off.p + p0, W.h_off.p + p0, n * sizeof(sg_off), hipMemcpyHostToDevice, st));
     int t_emit = vga_timer_begin(ctx, "subgraph_emit", 0, st);
     hipLaunchKernelGGL(k_sg_emit, dim3(waves), dim3(64), 0, st, (uint32_t)n, ix, words, nh, W.d_bitmaps.p + p0 * words, W.d_scratch.p, W.d_sum.p + p0,
-                       W.d_off.p + p0, B.d_handles.p, B.d_first_row.p, B.d_ntab.p, B.d_preds.p, B.d_sinks.p, B.d_seq.p);
+                       W.d_off.p + p0, B.d_handles.p, B.d_first_row.p, B.d_ntab.p, B.d_preds.p, B.d_sinks.p, B.d_seq.p,
+                       store.remain_rule == VGA_REMAIN_FIRST_OUT_EDGE ? 1 : 0);
     vga_timer_end(ctx, t_emit);
     SG_CHECK(hipGetLastError());
     SG_CHECK(hipMemcpyAsync(W.h_sum.p + p0, W.d_sum.p + p0, n * sizeof(sg_sum), hipMemcpyDeviceToHost, st));
@@ -511,9 +524,11 @@ int sg_run_part(vga_ctx *ctx, sg_ws &W, sg_store &store, int k, uint64_t p0, uin
 
 }  // namespace
 
-int sg_prepare(vga_ctx *ctx, const sg_desc *descs, const uint64_t *q_src, uint64_t n, uint64_t split, const char *d_reads, sg_store &store)
+int sg_prepare(vga_ctx *ctx, const sg_desc *descs, const uint64_t *q_src, uint64_t n, uint64_t split, const char *d_reads, int remain_rule,
+               sg_store &store)
 {
     store = sg_store();
+    store.remain_rule = remain_rule;
     if (n == 0) return VGA_OK;
     if (n >= (1ull << 31)) return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "too many chains in one call");
     (void)hipSetDevice(ctx->device);

@@ -23,7 +23,7 @@ struct sg_sum {
     uint32_t N;        // rows = graph bases
     uint32_t n_preds, n_sinks;
     uint32_t wlo, whi;  // words of the handle bitmap that hold set bits
-    uint32_t longest;   // graph bases on the longest source-sink path
+    uint32_t longest;   // `remain` of the virtual source: graph bases on the source-sink path the remain rule follows
     uint32_t life;      // largest edge span (in nodes) among the nodes that use the value-row ring
     uint32_t flags;     // bit 0: malformed for the POA kernels (in-degree > 255, too many rows)
     uint32_t pad[3];
@@ -49,6 +49,7 @@ struct sg_part {
 };
 struct sg_store {
     uint64_t n = 0, split = 0;
+    int remain_rule = 0;            // vga_poa_params.remain_rule the node tables are built for
     const sg_sum *sum = nullptr;    // host, n entries (valid for a part once it is ready)
     const sg_off *off = nullptr;    // host, n entries, offsets inside the problem's part
     const sg_off *d_off = nullptr;  // device copy
@@ -59,6 +60,7 @@ struct sg_store {
 
 // Runs the extraction for chains [0, split) of n on ctx->stream and waits for it.  `store` points into the context's
 // workspace and stays valid until the next call.  Returns VGA_OK or a negative VGA_ERR_*.
-int sg_prepare(vga_ctx *ctx, const sg_desc *descs, const uint64_t *q_src, uint64_t n, uint64_t split, const char *d_reads, sg_store &store);
+int sg_prepare(vga_ctx *ctx, const sg_desc *descs, const uint64_t *q_src, uint64_t n, uint64_t split, const char *d_reads, int remain_rule,
+               sg_store &store);
 // ... and for chains [split, n), on the workspace's side stream (it may run beside DP launches); waits for it.
 int sg_prepare_rest(vga_ctx *ctx, sg_store &store);

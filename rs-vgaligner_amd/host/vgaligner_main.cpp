@@ -30,7 +30,8 @@ const Flag MAP_FLAGS[] = {{"-i", "--index", true, "index"}, {"-f", "--input-file
                           {"", "--out-prefix", true, "out-prefix"}, {"", "--n-threads", true, "n-threads"},
                           // not in the reference: --device one GPU, --devices a list (one context + host thread each; an id may
                           // repeat; default: every visible GPU), --chunk-reads reads per batch (bounded memory; 0 = one batch)
-                          {"-d", "--device", true, "device"}, {"", "--devices", true, "devices"}, {"", "--chunk-reads", true, "chunk-reads"}};
+                          {"-d", "--device", true, "device"}, {"", "--devices", true, "devices"}, {"", "--chunk-reads", true, "chunk-reads"},
+                          {"", "--poa-remain", true, "poa-remain"}};
 
 template <size_t N>
 std::map<std::string, std::string> parse(const Flag (&flags)[N], int argc, char **argv, int first)
@@ -95,6 +96,12 @@ int map_main(int argc, char **argv)
     o.also_align = m.count("also-align") > 0;
     o.poa_aligner = need(m, "poa-aligner");  // cli.yml:169-175: required
     o.device = std::stoi(opt(m, "device", "0"));
+    if (m.count("poa-remain")) {  // which path the adaptive band's `remain` follows (include/vga_hip.h: VGA_REMAIN_*)
+        const std::string r = m["poa-remain"];
+        if (r == "longest") o.poa_remain_rule = VGA_REMAIN_LONGEST_PATH;
+        else if (r == "first-edge") o.poa_remain_rule = VGA_REMAIN_FIRST_OUT_EDGE;
+        else throw Error("--poa-remain takes longest or first-edge");
+    }
     o.also_validate = m.count("also-validate") > 0;
     if (o.also_validate) {
         if (!o.also_align) fprintf(stderr, "[vgaligner] --also-validate has no effect without --also-align (map.rs:150-186)\n");
@@ -137,7 +144,7 @@ int main(int argc, char **argv)
         if (argc >= 2 && !strcmp(argv[1], "map")) return map_main(argc, argv);
         fprintf(stderr, "vgaligner 0.7 (MI355X build)\nUSAGE:\n  vgaligner index -i <graph.gfa> -k <K> [-o prefix] [-e 100] [-m 100]\n"
                         "  vgaligner map -i <index> -f <reads.fa|fq> -p abpoa [-o prefix] [-g 1000] [-a 3] [-b 1] [-D -G <graph.gfa>] [-C]\n"
-                        "                [--devices 0,1,...] [--chunk-reads 32768]\n");
+                        "                [--devices 0,1,...] [--chunk-reads 32768] [--poa-remain longest|first-edge]\n");
         return 2;
     } catch (const std::exception &e) {
         fprintf(stderr, "vgaligner: %s\n", e.what());

@@ -112,6 +112,7 @@ struct MapOptions {
     bool also_align = false;             // -D
     uint64_t align_best_n = 1;           // -b
     std::string poa_aligner = "abpoa";   // -p
+    int poa_remain_rule = -1;            // --poa-remain longest|first-edge: vga_poa_params.remain_rule (-1: the library's default)
     int device = 0;                      // used when `devices` is empty and map_reads is handed a context
     // Multi-GPU / streaming (not in the reference, which is single-threaded): one context and one host thread per entry of
     // `devices` (an id may repeat: two contexts on one GPU), each mapping a contiguous slice of the reads balanced by bases, in

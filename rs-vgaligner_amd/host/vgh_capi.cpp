@@ -68,6 +68,7 @@ int vgh_map_reads(vga_ctx *ctx, void *h, uint64_t n, const char *const *names, c
         opt.also_align = also_align != 0;
         opt.align_best_n = align_best_n;
         if (const char *e = getenv("VGH_CHUNK_READS")) opt.chunk_reads = strtoull(e, nullptr, 10);  // (tests)
+        if (const char *e = getenv("VGH_POA_REMAIN")) opt.poa_remain_rule = atoi(e);                  // (tests)
         MapOutput o = map_reads(ctx, ((IndexBox *)h)->ix, in, opt, out_prefix ? out_prefix : "");
         if (chains_gaf) *chains_gaf = dup_str(o.chains_gaf);
         if (alignments_gaf) *alignments_gaf = dup_str(o.alignments_gaf);
@@ -134,6 +135,7 @@ int vgh_map_reads_multi(void *h, uint64_t n, const char *const *names, const cha
         opt.align_best_n = align_best_n;
         opt.devices.assign(devices, devices + n_devices);
         opt.chunk_reads = chunk_reads;
+        if (const char *e = getenv("VGH_POA_REMAIN")) opt.poa_remain_rule = atoi(e);  // (tests)
         MapOutput o = map_reads_multi(((IndexBox *)h)->ix, in, opt, out_prefix ? out_prefix : "");
         if (chains_gaf) *chains_gaf = dup_str(o.chains_gaf);
         if (alignments_gaf) *alignments_gaf = dup_str(o.alignments_gaf);

@@ -300,6 +300,7 @@ ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequenc
     if (opt.also_align) {
         vga_poa_params pp;
         vga_poa_default_params(&pp);
+        if (opt.poa_remain_rule >= 0) pp.remain_rule = opt.poa_remain_rule;
         vga_align_result *a = nullptr;
         if (vga_align_batch(b, m, (uint32_t)opt.align_best_n, &pp, &a) != VGA_OK) {
             const std::string e = vga_last_error(ctx);

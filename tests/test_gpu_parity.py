@@ -246,13 +246,17 @@ def test_poa_wide_rows_and_unbanded(oracle, ctx):
     _check_poa(oracle, ctx, [_rand_problem(rng, 30, 8) for _ in range(30)], pp2, op2)
 
 
-def _check_align(oracle, ctx, ix, reads):
+def _check_align(oracle, ctx, ix, reads, remain_rule=None):
     seqs = [r.seq for r in reads]
     b = ctx.batch(seqs)
     mo = b.map()
     compare_map(oracle, ix, mo, seqs)
-    al = b.align(mo)
-    cg, ag, st = oracle.map_reads(ix, [r.name for r in reads], seqs)
+    pp, omp = pkg().default_poa_params(), oracle.default_map_params()
+    if remain_rule is not None:
+        pp.remain_rule = remain_rule
+        omp.poa.remain_rule = remain_rule
+    al = b.align(mo, params=pp)
+    cg, ag, st = oracle.map_reads(ix, [r.name for r in reads], seqs, omp)
     lines = ag.splitlines()
     assert len(lines) == len(seqs)
     for r in range(len(seqs)):
@@ -268,6 +272,34 @@ def _check_align(oracle, ctx, ix, reads):
             int(al.path_length[r]), int(al.path_start[r]), int(al.path_end[r]), int(al.block_length[r]))
     assert al.poa_cells == st["poa_cells"] and al.poa_rows == st["poa_rows"]
     return al
+
+
+@pytest.mark.parametrize("rule", [0, 1], ids=["longest-path", "first-out-edge"])
+def test_remain_rule_of_the_adaptive_band(oracle, ctx, drb1, config4_gfa, monkeypatch, rule):
+    """vga_poa_params.remain_rule: which path `remain` (the diagonal term of the adaptive band) follows -- the longest path to
+    the sink, or the first out-edge in edge-list order (abPOA's heaviest-out-edge rule on unit weights; oracle/og_poa.c names
+    it an open choice).  Both through vga_poa_batch (node tables built by poa_prepare on the host) and through
+    vga_align_batch (built by k_sg_emit on the device, and by the host threads with VGA_SUBGRAPH=host), against the oracle."""
+    rng = random.Random(31 + rule)
+    pp, op = pkg().default_poa_params(), oracle.default_poa_params()
+    pp.remain_rule = rule
+    op.remain_rule = rule
+    problems = [_rand_problem(rng, rng.randint(2, 40), 8) for _ in range(80)] + [_rand_problem(rng, 60, 60) for _ in range(3)]
+    # two source nodes, two sinks, arms of very different length: the two rules give different bands here
+    problems.append((["ACGTACGTACGTACGTACGTACGTACGTACGT", "TT", "G" * 40, "ACGTAC", "CC"], [(0, 1), (0, 2), (1, 3), (2, 3), (2, 4)],
+                     "ACGTACGTACGTACGTACGTACGTACGTACGTTTACGTAC"))
+    _check_poa(oracle, ctx, problems, pp, op)
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    reads = pkg().readsim.simulate_reads(DRB1, 12, 2500, 0.03, 0.03, 0.04, seed=17) + pkg().readsim.config3_reads(DRB1, 2)
+    al = _check_align(oracle, ctx, ix, reads, remain_rule=rule)
+    monkeypatch.setenv("VGA_SUBGRAPH", "host")
+    al_h = _check_align(oracle, ctx, ix, reads[:6], remain_rule=rule)
+    monkeypatch.delenv("VGA_SUBGRAPH")
+    assert al_h.cigar == al.cigar[:6]
+    ix4 = oracle.Index(oracle.Graph.from_gfa(config4_gfa), 11)
+    upload_oracle_index(ctx, ix4)
+    _check_align(oracle, ctx, ix4, pkg().readsim.simulate_reads(config4_gfa, 5, 3000, 0.03, 0.03, 0.04, seed=5), remain_rule=rule)
 
 
 def test_align_short_reads(oracle, ctx, drb1):
