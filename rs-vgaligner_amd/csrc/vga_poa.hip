@@ -34,6 +34,7 @@
 
 #include "vga_poa_kernels.hpp"
 #include "vga_poa_t4.hpp"
+#include "vga_poa_t5.hpp"
 
 // One workgroup per staged problem: copies its node table, predecessor rows, sink rows, bases and query from the device
 // store of vga_subgraph.hip (and the batch's reads) to where this sub-batch's poa_prob says they are.
@@ -503,6 +504,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         }
         auto chk = [&](hipError_t e) { if (e != hipSuccess && launch_err == hipSuccess) launch_err = e; };
         bool sub_t4 = false;   // ... k_poa_dp_t4 (its own direction-byte encoding)
+        bool sub_t5 = false;   // ... k_poa_dp_t5 (direction dwords)
         bool sub_fused = false;  // ... and its DP kernel does the traceback as well
         if (malformed || dev_failed || i1 == i0) return {i0, i0, 0.0, slot, 0};
         const int oset = (int)(S.uses++ & 1u);
@@ -619,7 +621,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             }
             // workgroup size
             int nt = mq >= 3072 ? 512 : (mq >= 768 ? 256 : 128);
-            auto lds_of = [&](int t) { return t4 ? poa_t4_lds_bytes(hg_cols, lds_cols, t) : poa_lds_bytes(lds_cols, t); };
+            // k_poa_dp_t5 (vga_poa_t5.hpp), the default: the same rows under a leaderless row loop; its packed gap-byte arithmetic
+            // needs 4 o_k + 1 <= 128 and 4 (o2 + e2) + 1 <= 255.  VGA_POA_KERNEL=t4 selects k_poa_dp_t4
+            const bool t5 = t4 && !(force && strstr(force, "t4")) && P.o1 <= 31 && P.o2 <= 31 && 4 * (P.o2 + P.e2) + 1 <= 255 && 4 * (P.o1 + P.e1) <= 255;
+            auto lds_of = [&](int t) { return t5 ? poa_t5_lds_bytes(hg_cols, lds_cols, t) : (t4 ? poa_t4_lds_bytes(hg_cols, lds_cols, t) : poa_lds_bytes(lds_cols, t)); };
             const size_t lds_limit = 160 * 1024 - 256;
             if (t4) {
                 // the one that keeps the most waves resident (LDS and 16 wave slots per CU at this kernel's register count
@@ -660,18 +665,29 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             const size_t lds = lds_of(nt);
             if (tr.on)
                 fprintf(stderr, "[vga-trace] poa: launch %u problems, NT %d, %s, window %u of %u columns, width estimate mean %.0f max %.0f, LDS %zu B\n",
-                        nb, nt, t4 ? "k_poa_dp_t4" : "k_poa_dp_lds", hg_cols, lds_cols, mean_w, mw, lds);
+                        nb, nt, t5 ? "k_poa_dp_t5" : (t4 ? "k_poa_dp_t4" : "k_poa_dp_lds"), hg_cols, lds_cols, mean_w, mw, lds);
             (void)hipGetLastError();  // a launch failure below must be this launch's, not an older ignored status
 #define POA_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_sink.p, P, S.d_rows.p, pool_base,          \
                  W.d_next.p + slot, half_pool, S.d_outs.p, lds_cols
             sub_t4 = t4;
+            sub_t5 = t5;
             if (t4) {
+                const poa_t5_args t5a = {S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_rows.p, pool_base, W.d_next.p + slot, half_pool,
+                                         S.d_outs.p, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr), W.d_arena_ctr.p,
+                                         W.d_arena_flag.p, arena_size, (arena ? n_arenas : 0u), lds_cols, hg_cols, win_mask, P};
+                (void)t5a;
 #define POA_T4_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, P, S.d_rows.p, pool_base, W.d_next.p + slot, half_pool,   \
                     S.d_outs.p, lds_cols, hg_cols, win_mask, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr),       \
                     (arena ? n_arenas : 0u), arena_size, W.d_arena_ctr.p, W.d_arena_flag.p
 #define POA_T4_LAUNCH(T)                                                                                                     \
     case T:                                                                                                                  \
-        if (def_pen) {                                                                                                       \
+        if (t5 && def_pen) {                                                                                                 \
+            chk(hipFuncSetAttribute((const void *)k_poa_dp_t5<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_poa_dp_t5<T, true>), dim3(nb), dim3(T), lds, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t5a);                                    \
+        } else if (t5) {                                                                                                     \
+            chk(hipFuncSetAttribute((const void *)k_poa_dp_t5<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_poa_dp_t5<T, false>), dim3(nb), dim3(T), lds, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t5a);                                   \
+        } else if (def_pen) {                                                                                                     \
             chk(hipFuncSetAttribute((const void *)k_poa_dp_t4<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL((k_poa_dp_t4<T, true>), dim3(nb), dim3(T), lds, st, POA_T4_ARGS);                            \
         } else {                                                                                                             \
@@ -704,6 +720,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         if (sub_fused) {
             // the DP kernel's first wave already walked each problem back
         }
+        else if (sub_t5)
+            hipLaunchKernelGGL(k_poa_traceback_wave<2>, dim3(nb), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
+                               pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, 0);
         else if (sub_t4)
             hipLaunchKernelGGL(k_poa_traceback_wave<1>, dim3(nb), dim3(64), 0, st, nb, S.d_probs.p, S.d_rows.p, S.d_preds.p,
                                pool_base, S.d_outs.p, S.d_ops.p, S.d_orow.p, 0);

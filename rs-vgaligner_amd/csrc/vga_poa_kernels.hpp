@@ -109,6 +109,17 @@ __device__ __forceinline__ int poa_wave_scan_max(int v)
     t = poa_dpp<0x143, 0xc>(INT32_MIN, v); v = t > v ? t : v;  // row_bcast:31 -> rows 2,3
     return v;
 }
+__device__ __forceinline__ int poa_wave_scan_min(int v)
+{
+    int t;
+    t = poa_dpp<0x111, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = poa_dpp<0x112, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = poa_dpp<0x114, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = poa_dpp<0x118, 0xf>(INT32_MAX, v); v = t < v ? t : v;
+    t = poa_dpp<0x142, 0xa>(INT32_MAX, v); v = t < v ? t : v;
+    t = poa_dpp<0x143, 0xc>(INT32_MAX, v); v = t < v ? t : v;
+    return v;
+}
 __device__ __forceinline__ int poa_wave_shr1(int v) { return poa_dpp<0x138, 0xf>(POA_IDENT, v); }  // wave_shr:1
 
 template <int NT, int CPT, bool STAMP = false>
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(NT) void k_poa_dp_lds(
 }
 
 // K4b: one lane per problem.  ops are written in reverse (sink -> source) order.
-// ENC 0: direction bytes of k_poa_dp_lds / k_poa_dp_pk; ENC 1: of k_poa_dp_t4 (vga_poa_t4.hpp)
+// ENC 0: direction bytes of k_poa_dp_lds; ENC 1: of k_poa_dp_t4 (vga_poa_t4.hpp); ENC 2: direction dwords of k_poa_dp_t5
 struct tb_code { int hts, fsel, eo1, eo2, fo1, fo2; };
 template <int ENC>
 __device__ __forceinline__ tb_code tb_decode(int code)
@@ -596,6 +607,21 @@ __device__ __forceinline__ tb_code tb_decode(int code)
         c.eo1 = (code >> 3) & 1; c.eo2 = (code >> 2) & 1;
         c.fo1 = ((code >> 1) & 1) ^ 1; c.fo2 = (code & 1) ^ 1;
     }
+    return c;
+}
+// ENC 2 (k_poa_dp_t5): the dword of four cells.  Byte k: [5:4] tag of H (3 Ht, 1 F1, 0 F2), [3:2] tag of Ht (2 M, 1 E1, 0 E2),
+// [1] / [0] F1 / F2 of the cell did not open.  "E1 / E2 of a successor opens from cell k": bit 7 (k < 2) or 6 (k >= 2) of bytes
+// 2 (k & 1) and 2 (k & 1) + 1.
+__device__ __forceinline__ tb_code tb_decode2(uint32_t d, int k)
+{
+    tb_code c;
+    const int b = (int)(d >> (8 * k)) & 0xff;
+    const int th = (b >> 4) & 3;
+    c.hts = 2 - ((b >> 2) & 3);
+    c.fsel = th == 3 ? 0 : (th == 1 ? 1 : 2);
+    c.fo1 = ((b >> 1) & 1) ^ 1; c.fo2 = (b & 1) ^ 1;
+    const int eb = 16 * (k & 1) + (k < 2 ? 7 : 6);
+    c.eo1 = (int)(d >> eb) & 1; c.eo2 = (int)(d >> (eb + 8)) & 1;
     return c;
 }
 
@@ -697,9 +723,10 @@ __device__ __forceinline__ void poa_traceback_wave(
             const uint32_t npred = T.np[t];
             const bool first = npred != 0;
             const int np = first ? (int)npred : 1;
-            const int code = (int)((T.dir[t][off >> 2] >> (8 * (off & 3))) & 0xffu) ^ code_xor;
-            const tb_code dc = tb_decode<ENC>(code);
-            if (ENC == 1 && pend_e) {  // arrived through a deletion: this cell says whether that gap opened from it
+            tb_code dc;
+            if constexpr (ENC == 2) dc = tb_decode2(T.dir[t][off >> 2], off & 3);
+            else dc = tb_decode<ENC>((int)((T.dir[t][off >> 2] >> (8 * (off & 3))) & 0xffu) ^ code_xor);
+            if (ENC >= 1 && pend_e) {  // arrived through a deletion: this cell says whether that gap opened from it
                 if (pend_e == 1 ? dc.eo1 : dc.eo2) st = 0;
                 pend_e = 0;
             }
@@ -731,7 +758,7 @@ __device__ __forceinline__ void poa_traceback_wave(
                 } else {
                     const int open = src == 1 ? dc.eo1 : dc.eo2;
                     emit(2, i);
-                    if (ENC == 1) { st = src; pend_e = src; }
+                    if (ENC >= 1) { st = src; pend_e = src; }
                     else st = open ? 0 : src;
                     i = p;
                 }

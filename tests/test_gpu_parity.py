@@ -464,6 +464,7 @@ def _fallback_problems(rng):
 
 
 @pytest.mark.parametrize("env", [{"VGA_POA_ARENAS": "0"}, {"VGA_POA_ARENAS": "0", "VGA_POA_SLOTS": "1"}, {"VGA_POA_KERNEL": "unpacked"},
+                                 {"VGA_POA_KERNEL": "t4"}, {"VGA_POA_KERNEL": "t4", "VGA_POA_ARENAS": "0"}, {"VGA_POA_KERNEL": "generic"},
                                  {"VGA_POA_TB": "wave"}, {"VGA_POOL_BYTES": "300000000"}, {"VGA_POA_SUB": "7"}, {"VGA_POA_WINDOW": "256"},
                                  {"VGA_POA_NT": "512"}, {"VGA_POA_NT": "1024"}, {"VGA_POA_NT": "512", "VGA_POA_ARENAS": "0"},
                                  {"VGA_SG_SPLIT": "1"}, {"VGA_SG_SPLIT": "2", "VGA_POA_SUB": "2", "VGA_POOL_BYTES": "300000000", "VGA_POA_ARENAS": "0"}],
