@@ -396,7 +396,32 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
             for (int c0 = 0; c0 < W; c0 += STEP) {
                 const int c = c0 + 4 * tid;
                 const int j0 = bal + c;
-                if (j0 <= end) {
+                if (j0 <= end && np == 1) {
+                    // one predecessor: its cells as they are, 4 POA_NEG outside its band
+                    const int bp = __builtin_amdgcn_readfirstlane(R[sp].beg), ep = __builtin_amdgcn_readfirstlane(R[sp].end);
+                    const uint8_t *Vq = pool + t5_uniform64(R[sp].voff);
+                    const int balq = bp & ~3;
+                    const int Wq = (ep - balq + 1 + 3) & ~3;
+                    const int idx = j0 - balq;
+                    int4 hv = make_int4(T4_NEG, T4_NEG, T4_NEG, T4_NEG);
+                    uint2 gg = make_uint2(0u, 0u);
+                    if (idx >= 0 && idx < Wq) {
+                        hv = *(const int4 *)((const int32_t *)Vq + idx);
+                        gg = *(const uint2 *)(Vq + 4ll * Wq + 2ll * idx);
+                    }
+                    const unsigned pspan = (unsigned)(ep - bp);
+                    const bool in0 = (unsigned)(j0 - bp) <= pspan, in1 = (unsigned)(j0 + 1 - bp) <= pspan, in2 = (unsigned)(j0 + 2 - bp) <= pspan,
+                               in3 = (unsigned)(j0 + 3 - bp) <= pspan;
+                    hv.x = in0 ? hv.x : T4_NEG; hv.y = in1 ? hv.y : T4_NEG; hv.z = in2 ? hv.z : T4_NEG; hv.w = in3 ? hv.w : T4_NEG;
+                    gg.x = (in0 ? gg.x & 0xffffu : 0u) | (in1 ? gg.x & 0xffff0000u : 0u);
+                    gg.y = (in2 ? gg.y & 0xffffu : 0u) | (in3 ? gg.y & 0xffff0000u : 0u);
+                    *(int4 *)(Hs + (j0 & win_mask)) = hv;
+                    *(uint2 *)(Gs + (j0 & win_mask)) = gg;
+                    if (c == 0 && bal > 0) {
+                        const int wl = (idx >= 1 && idx - 1 < Wq) ? ((const int32_t *)Vq)[idx - 1] : 0;
+                        Hs[(bal - 1) & win_mask] = (unsigned)(j0 - 1 - bp) <= pspan ? wl : T4_NEG;
+                    }
+                } else if (j0 <= end) {
                     int hm[4], x1[4], x2[4], ah[4], a1[4], a2[4];
                     int hl = T4_NEG, ahl = 0;
 #pragma unroll
