@@ -139,6 +139,20 @@ typedef struct {
 int vga_map_batch(vga_batch *b, const vga_map_params *params, vga_map_result **out);
 void vga_map_result_free(vga_map_result *r);
 
+/* The path column of every chain's GAF record -- GAFAlignment::from_chain (src/align.rs:762-911) with AnchorPosOnGraph::new
+ * (src/chain.rs:90-127): for each anchor of a chain, in order, "(>N:off,>N:off)," = node id and offset inside the node of
+ * target_begin and of the inclusive target_end.  `text` holds the fields of all chains back to back, without terminators;
+ * chain c's field is text[text_off[c] .. text_off[c + 1]) (empty for a placeholder chain).  Forward-strand anchors only
+ * (vga_map_params.only_forward = 1, the reference's only live setting). */
+typedef struct {
+    uint64_t n_chains;
+    uint64_t *text_off; /* n_chains + 1 */
+    char *text;
+    float ms_total;
+} vga_chain_text;
+int vga_chain_paths_text(vga_ctx *ctx, const vga_map_result *chains, vga_chain_text **out);
+void vga_chain_text_free(vga_chain_text *t);
+
 /* ---- align: chain -> subgraph -> POA ---------------------------------------------------------- */
 typedef struct {
     int32_t match;     /* 2  */

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "vga_ctx_create", "vga_ctx_destroy", "vga_last_error", "vga_ctx_synchronize", "vga_abi_version",
     "vga_index_upload", "vga_batch_create", "vga_batch_destroy", "vga_map_default_params", "vga_map_batch",
     "vga_map_result_free", "vga_poa_default_params", "vga_poa_result_free", "vga_poa_batch", "vga_align_batch",
-    "vga_align_result_free", "vga_last_kernel_times",
+    "vga_align_result_free", "vga_last_kernel_times", "vga_chain_paths_text", "vga_chain_text_free",
 ]
 
 
@@ -63,6 +63,10 @@ class PoaParams(C.Structure):
 
 
 _P = C.POINTER
+
+
+class ChainText(C.Structure):
+    _fields_ = [("n_chains", C.c_uint64), ("text_off", C.POINTER(C.c_uint64)), ("text", C.POINTER(C.c_char)), ("ms_total", C.c_float)]
 
 
 class MapResult(C.Structure):
@@ -135,6 +139,8 @@ def load_library():
     L.vga_align_batch.argtypes = [vp, _P(MapResult), C.c_uint32, _P(PoaParams), _P(_P(AlignResult))]
     L.vga_align_result_free.argtypes = [_P(AlignResult)]
     L.vga_last_kernel_times.argtypes = [vp, _P(KernelTime), C.c_int]
+    L.vga_chain_paths_text.argtypes = [vp, _P(MapResult), _P(_P(ChainText))]
+    L.vga_chain_text_free.argtypes = [_P(ChainText)]
     _lib = L
     return L
 
@@ -438,6 +444,19 @@ class Context:
                                          _u32p(esa), _u32p(eda), _u64p(query_off), "".join(qs).encode(), C.byref(p),
                                          C.byref(out)))
         return PoaOut(self.L, out)
+
+    def chain_paths_text(self, chains: "MapOut") -> List[bytes]:
+        """the path column of every chain's GAF record (vga_chain_paths_text), one bytes object per chain"""
+        out = _P(ChainText)()
+        self._check(self.L.vga_chain_paths_text(self.h, chains._ptr, C.byref(out)))
+        try:
+            t = out.contents
+            n = int(t.n_chains)
+            off = [int(t.text_off[i]) for i in range(n + 1)]
+            raw = C.string_at(t.text, off[n]) if off[n] else b""
+            return [raw[off[i]:off[i + 1]] for i in range(n)]
+        finally:
+            self.L.vga_chain_text_free(out)
 
     def kernel_times(self):
         arr = (KernelTime * 32)()

@@ -381,12 +381,6 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
             }
             return rc2;
         };
-        // base `off` of the node-th handle of problem p (seq_from_handle, src/index.rs:503-533)
-        feed.row_base = [&](uint64_t p, uint32_t node, uint32_t off) -> char {
-            const handle_t h = store.of(p).h_handles[store.off[p].node0 + node];
-            const uint32_t id = h >> 1, s = ctx->index.node_start[id - 1], e = ctx->index.node_start[id];
-            return (h & 1) ? iv_all.complement(ctx->index.seq_fwd[e - 1 - off]) : ctx->index.seq_fwd[s + off];
-        };
         tr.mark("subgraphs on the GPU");
     }
     if (!on_device) feed.prepare = [&](const uint32_t *ids, uint64_t cnt) {

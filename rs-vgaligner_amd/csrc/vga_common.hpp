@@ -78,6 +78,8 @@ struct vga_ctx {
     void (*poa_ws_free)(void *) = nullptr;
     void *sg_ws = nullptr;
     void (*sg_ws_free)(void *) = nullptr;
+    void *gaf_ws = nullptr;
+    void (*gaf_ws_free)(void *) = nullptr;
     // live read batches: vga_ctx_destroy releases their device memory and detaches them, so a batch handle may be
     // destroyed after its context
     std::vector<struct vga_batch *> batches;

@@ -99,6 +99,7 @@ extern "C" void vga_ctx_destroy(vga_ctx *ctx)
     if (ctx->map_ws && ctx->map_ws_free) ctx->map_ws_free(ctx->map_ws);
     if (ctx->poa_ws && ctx->poa_ws_free) ctx->poa_ws_free(ctx->poa_ws);
     if (ctx->sg_ws && ctx->sg_ws_free) ctx->sg_ws_free(ctx->sg_ws);
+    if (ctx->gaf_ws && ctx->gaf_ws_free) ctx->gaf_ws_free(ctx->gaf_ws);
     vga_index_release(ctx->index);
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

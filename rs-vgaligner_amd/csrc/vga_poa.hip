@@ -30,6 +30,8 @@
 #include <cstddef>
 #include <type_traits>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "vga_poa_kernels.hpp"
@@ -181,26 +183,106 @@ struct poa_slot {
     struct out_set {
         vga_hbuf<uint32_t> h_orow;
         vga_hbuf<uint8_t> h_ops;
+        vga_hbuf<char> h_seq;     // device store: the bases of the sub-batch's problems (row r of a problem is byte seq0 + r - 1)
         vga_hbuf<poa_out> h_outs;
     } outs[2];
     uint32_t uses = 0;
 };
 
+// The traceback pool: SEGMENTS of HBM, allocated one after the other by a thread of its own (`grower`) so that the first launch
+// does not wait for all of it -- on a GPU whose memory was used before, the driver clears what it hands out at ~40 GB/s, and
+// rounds 1-2 spent 0.4-7 s in one 257 GB hipMalloc before the first kernel of a process (and 1.6 s in the hipFree at its end).
+// k_poa_dp_t5 takes the segments' 1 MiB chunks through a device-side free list (vga_poa_kernels.hpp: poa_chunk_pool);
+// classic launches (k_poa_dp_t4 / k_poa_dp_lds, problems the chunk mode hands back) bump-allocate inside whole segments --
+// never at the same time as chunk-mode launches.
+#define POA_SEG_LOG2 32  // 4 GiB segments (4 096 chunks)
+#define POA_MAX_SEGS 80
 struct poa_ws {
     poa_slot slot[POA_SLOTS];
     vga_dbuf<unsigned long long> d_next;
     vga_hbuf<unsigned long long> h_next;
-    vga_dbuf<unsigned long long> d_arena_ctr;  // arena mode: one bump counter and one busy flag per arena
-    vga_dbuf<uint32_t> d_arena_flag;
-    uint8_t *pool = nullptr;
-    uint64_t pool_size = 0;
     hipStream_t extra[POA_SLOTS] = {};  // streams of slots 1.. (slot 0 runs on the context's stream)
     double pool_scale = 1.0;   // measured pool bytes / estimated bytes, adapted after every sub-batch
+    // segments (guarded by mu)
+    struct seg_t { uint8_t *p; uint64_t size; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<seg_t> segs;
+    uint64_t pool_size = 0;     // bytes in segs
+    uint64_t grow_target = 0;   // the grower stops at this many bytes
+    uint8_t *classic = nullptr; // the classic pool: one contiguous piece (launches that do not run in chunk-pool mode)
+    uint64_t classic_size = 0;
+    bool growing = false, grow_failed = false;
+    std::thread grower;
+    int device = 0;
+    uint64_t seg_bytes = 1ull << POA_SEG_LOG2;
+    // chunk pool (device side)
+    vga_dbuf<unsigned long long> d_head;  // the free-list heads (POA_LISTS of them, a cache line apart), then the statistics
+    vga_dbuf<uint32_t> d_next_chunk, d_slot_flag;
+    vga_hbuf<uint64_t> h_seg_base;        // staging of ...
+    vga_dbuf<uint64_t> d_seg_base;        // ... the segment table the kernels read (an entry is copied before its chunks are listed)
+    hipStream_t add_stream = nullptr;
+    uint32_t chunks_listed = 0;           // chunks of segments [0, segs_listed) are in the free list
+    uint64_t polls = 0, empties_seen = 0; // how often the kernels found the free list empty (poa_chunk_pool::stats[1]), as last read
+    size_t segs_listed = 0;
+    uint8_t *state = nullptr;             // the state regions
+    uint64_t state_bytes = 0;
+    hipError_t reset_lists()  // every free list empty, statistics zero
+    {
+        std::vector<unsigned long long> init(POA_LISTS * POA_LIST_STRIDE + 16, 0ull);
+        for (int l = 0; l < POA_LISTS; l++) init[(size_t)l * POA_LIST_STRIDE] = (unsigned long long)POA_NIL;
+        return hipMemcpy(d_head.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
+    }
+    void stop_grower()
+    {
+        { std::lock_guard<std::mutex> lk(mu); grow_target = 0; }
+        if (grower.joinable()) grower.join();
+    }
     ~poa_ws()
     {
-        if (pool) (void)hipFree(pool);
+        stop_grower();
+        for (auto &g : segs) (void)hipFree(g.p);
+        if (classic) (void)hipFree(classic);
+        if (state) (void)hipFree(state);
+        if (add_stream) (void)hipStreamDestroy(add_stream);
         for (int i = 0; i < POA_SLOTS; i++)
             if (extra[i]) (void)hipStreamDestroy(extra[i]);
+    }
+    // asks for a pool of at least `target` bytes; returns at once (the grower thread allocates)
+    void request(uint64_t target)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (target <= pool_size || (growing && target <= grow_target)) return;
+        grow_target = target;
+        grow_failed = false;
+        if (growing) return;
+        if (grower.joinable()) grower.join();
+        growing = true;
+        grower = std::thread([this]() {
+            (void)hipSetDevice(device);
+            for (;;) {
+                uint64_t want;
+                {
+                    std::lock_guard<std::mutex> lk2(mu);
+                    if (pool_size >= grow_target || segs.size() >= POA_MAX_SEGS) { growing = false; cv.notify_all(); return; }
+                    want = std::min<uint64_t>(seg_bytes, (grow_target - pool_size + POA_CHUNK - 1) & ~(POA_CHUNK - 1));
+                }
+                uint8_t *q = nullptr;
+                const hipError_t e = hipMalloc((void **)&q, want);
+                std::lock_guard<std::mutex> lk2(mu);
+                if (e != hipSuccess) { (void)hipGetLastError(); growing = false; grow_failed = true; cv.notify_all(); return; }
+                segs.push_back({q, want});
+                pool_size += want;
+                cv.notify_all();
+            }
+        });
+    }
+    // waits until `bytes` of pool exist or the grower has stopped; returns what exists
+    uint64_t wait_for(uint64_t bytes)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return pool_size >= bytes || !growing; });
+        return pool_size;
     }
 };
 
@@ -361,41 +443,32 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     } while (0)
     POA_CHECK(W.h_next.reserve(POA_SLOTS));
     POA_CHECK(W.d_next.reserve(POA_SLOTS));
-    // ---- the pool: sized from the first prepared problems, grown generously (a hipMalloc of this size costs seconds)
+    // ---- footprint probe: the first prepared problems (the largest, in launch order)
     const uint64_t n_probe = std::min<uint64_t>(n, 512);
     ensure(0, n_probe);
     if (malformed) return malformed_error();
+    double probe_sum = 0, probe_big = 0;
+    for (uint64_t i = 0; i < n_probe; i++) { probe_sum += est[order[i]]; probe_big = std::max(probe_big, est[order[i]]); }
+    const double probe_mean = probe_sum / (double)n_probe;
+    W.device = ctx->device;
+    // what this context may take of the GPU: everything else it allocates (staging of three sub-batches, the subgraph store,
+    // the map workspace) keeps 15 % of what is free, at least 16 GB -- two processes sharing a GPU otherwise starve each other
+    uint64_t avail_pool = 0;
     {
-        double probe = 0;
-        for (uint64_t i = 0; i < n_probe; i++) probe += est[order[i]];
-        const double want_d = probe / (double)n_probe * (double)n * W.pool_scale * 1.3 + (double)n * 3.0 * (double)POA_CHUNK;
-        uint64_t want = (uint64_t)want_d + 64 * POA_CHUNK;
-        const char *env_pool = getenv("VGA_POOL_BYTES");
-        if (env_pool) want = std::min<uint64_t>(want, strtoull(env_pool, nullptr, 10));
-        if (W.pool_size < want) {
-            size_t free_b = 0, total_b = 0;
-            POA_CHECK(hipMemGetInfo(&free_b, &total_b));
-            // leave room for everything else this context allocates (staging of three sub-batches, the subgraph store, the
-            // map workspace): 15 % of what is free, at least 16 GB -- two processes sharing a GPU otherwise starve each other
-            const uint64_t have = free_b + W.pool_size;
-            const uint64_t reserve = std::max<uint64_t>((uint64_t)((double)have * 0.15), 16ull << 30);
-            uint64_t avail = have > reserve ? have - reserve : have / 4;
-            // several contexts on one GPU (vgaligner map --devices 0,0: the driver sets this to 1 / their number) share it
-            if (const char *fr = getenv("VGA_POOL_FRACTION")) {
-                const double f = atof(fr);
-                if (f > 0.0 && f < 1.0) avail = (uint64_t)((double)avail * f);
-            }
-            const uint64_t target = std::min(std::max<uint64_t>(2 * want, 8ull << 30), avail) & ~(POA_CHUNK - 1);
-            if (target > W.pool_size) {
-                if (W.pool) { (void)hipFree(W.pool); W.pool = nullptr; W.pool_size = 0; }
-                if (target < 64 * POA_CHUNK)
-                    return vga_set_error(ctx, VGA_ERR_NOMEM, "only %llu bytes of HBM free for the traceback pool", (unsigned long long)free_b);
-                POA_CHECK(hipMalloc((void **)&W.pool, target));
-                W.pool_size = target;
-            }
+        size_t free_b = 0, total_b = 0;
+        POA_CHECK(hipMemGetInfo(&free_b, &total_b));
+        uint64_t have;
+        { std::lock_guard<std::mutex> lk(W.mu); have = free_b + W.pool_size; }
+        have += W.classic_size;
+        const uint64_t reserve = std::max<uint64_t>((uint64_t)((double)have * 0.15), 16ull << 30);
+        avail_pool = have > reserve ? have - reserve : have / 4;
+        // several contexts on one GPU (vgaligner map --devices 0,0: the driver sets this to 1 / their number) share it
+        if (const char *fr = getenv("VGA_POOL_FRACTION")) {
+            const double f = atof(fr);
+            if (f > 0.0 && f < 1.0) avail_pool = (uint64_t)((double)avail_pool * f);
         }
+        if (const char *env_pool = getenv("VGA_POOL_BYTES")) avail_pool = std::min<uint64_t>(avail_pool, strtoull(env_pool, nullptr, 10));
     }
-    tr.mark("pool");
     // Two sub-batches are in flight at any time, one per stream, each carving from its own half of the pool: while one
     // drains (its last workgroups, then the latency-bound traceback and the copies back) the other one's
     // workgroups fill the CUs.
@@ -410,7 +483,17 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         return vga_set_error(ctx, VGA_ERR_UNSUPPORTED, "query of %u bases: only k_poa_dp_t4 (default penalties range) handles queries beyond ~131 kbp", max_q);
     // traceback: fused into the DP kernel (default), or VGA_POA_TB=wave: a kernel of its own after the DP
     const bool tb_fused = !getenv("VGA_POA_TB") || strstr(getenv("VGA_POA_TB"), "fused");
-    const bool arena_wanted = t4_k && tb_fused && !(getenv("VGA_POA_ARENAS") && atoi(getenv("VGA_POA_ARENAS")) == 0);
+    // k_poa_dp_t5 (vga_poa_t5.hpp), the default: the same rows under a leaderless row loop; its packed gap-byte arithmetic
+    // needs 4 o_k + 1 <= 128.  VGA_POA_KERNEL=t4 selects k_poa_dp_t4
+    const bool t5_k = t4_k && !(force_k && strstr(force_k, "t4")) && params->gap_open1 <= 31 && params->gap_open2 <= 31 &&
+                      4 * (params->gap_open2 + params->gap_ext2) + 1 <= 255;
+    // chunk-pool mode (k_poa_dp_t5 with its fused traceback; VGA_POA_ARENAS=0 switches it off): every row of a problem must
+    // fit a chunk (a multi-predecessor row has four planes), and a state region holds the ring, the scratch rows and a few
+    // kept value rows
+    const uint64_t maxrow_all = (6ull * (uint64_t)((max_q + 8) & ~3u) + 15ull) & ~15ull;
+    const uint64_t state_size = (maxrow_all * (POA_RING_SPAN + 1) + 12ull * poa_lds_cols(max_q) + 4096ull + 65535ull) & ~65535ull;
+    const bool arena_wanted = t5_k && tb_fused && !(getenv("VGA_POA_ARENAS") && atoi(getenv("VGA_POA_ARENAS")) == 0) &&
+                              4ull * ((uint64_t)max_q + 8) <= POA_CHUNK;
     // classic mode: two sub-batches in flight (three are no faster, four overflow their pool quarters).  Arena mode: the
     // pool is not split and a third slot only costs staging buffers (round 1 ran three throughout: +1.4 % on config 3 with
     // first-in-first-out completion; with launches handled in the order they finish, round 2, that reversed).
@@ -429,33 +512,128 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         if (!W.extra[i]) POA_CHECK(hipStreamCreateWithFlags(&W.extra[i], hipStreamNonBlocking));
         sarr[i] = W.extra[i];
     }
-    const uint64_t half_pool = (W.pool_size / (uint64_t)n_slots) & ~(POA_CHUNK - 1);  // one slot's segment of the pool
-
-    // ---- arena mode (the default with k_poa_dp_t4 / k_poa_dp_t5 and their fused traceback): the whole pool is cut into arenas, a
-    // workgroup holds one from its first row to the end of its traceback.  No launch has to wait for another one's
-    // pool segment, so sub-batches are cut for the host pipeline only and workgroups of consecutive launches fill the
-    // CUs back to back.  Problems that would not fit an arena (and the ones that turn out not to) are collected and run
-    // at the end in classic mode, which gives each of them as much of the pool as it needs.
-    uint32_t n_arenas = 0;
-    uint64_t arena_size = 0;
+    // ---- chunk-pool mode: the state regions now, the chunk segments on the grower thread (the first launch starts as soon
+    // as one segment is there; its workgroups all begin with empty hands).  The pool should hold what the resident
+    // workgroups have written so far: about six per CU, each on average two thirds through a problem of the probe's mean
+    // size -- a workgroup that finds the free list empty waits for chunks to come back (and gives its problem up after a
+    // bounded wait: the classic pass takes it).
+    uint32_t n_arenas = 0;  // state regions (0: classic mode for the whole call)
+    poa_chunk_pool CP = {};
     if (arena_wanted) {
-        // an arena should hold the largest of the probed problems with a margin; more arenas than workgroups can be
-        // resident (16 per CU at most) are of no use, fewer than 4 per CU would leave most of the GPU waiting for one
-        double big = 0;
-        for (uint64_t i = 0; i < n_probe; i++) big = std::max(big, est[order[i]]);
-        const double want_arena = big * W.pool_scale * 1.3 + 4.0 * (double)POA_CHUNK;
-        uint64_t na = (uint64_t)((double)W.pool_size / want_arena);
-        na = std::min<uint64_t>(na, 16ull * (uint64_t)ctx->n_cu);
-        if (const char *e = getenv("VGA_POA_ARENAS")) na = std::min<uint64_t>(na, strtoull(e, nullptr, 10));
-        if (na >= 4ull * (uint64_t)ctx->n_cu || na >= n) {
-            n_arenas = (uint32_t)na;
-            arena_size = (W.pool_size / na) & ~(POA_CHUNK - 1);
-            POA_CHECK(W.d_arena_ctr.reserve(n_arenas));
-            POA_CHECK(W.d_arena_flag.reserve(n_arenas));
-            POA_CHECK(hipMemset(W.d_arena_flag.p, 0, n_arenas * sizeof(uint32_t)));
+        uint64_t ns = std::min<uint64_t>(16ull * (uint64_t)ctx->n_cu, std::max<uint64_t>(n, 64));  // (16 two-wave workgroups per CU at most)
+        if (const char *e = getenv("VGA_POA_ARENAS")) ns = std::min<uint64_t>(ns, std::max<uint64_t>(1, strtoull(e, nullptr, 10)));
+        while (ns > 1 && ns * state_size > avail_pool / 4) ns /= 2;
+        const uint64_t resident = std::min<uint64_t>(n, 6ull * (uint64_t)ctx->n_cu);
+        double fill = 0.7;
+        if (const char *e = getenv("VGA_POOL_FILL")) fill = atof(e);
+        uint64_t want = (uint64_t)((double)resident * probe_mean * W.pool_scale * fill) + 64 * POA_CHUNK;
+        want = std::max<uint64_t>(want, (uint64_t)(probe_big * W.pool_scale * 1.5));
+        want = std::min<uint64_t>(want, avail_pool > ns * state_size ? avail_pool - ns * state_size : avail_pool / 2);
+        want = (want + POA_CHUNK - 1) & ~(POA_CHUNK - 1);
+        if (ns * state_size <= avail_pool / 2 && want >= 16 * POA_CHUNK) {
+            if (W.state_bytes < ns * state_size) {
+                if (W.state) { (void)hipFree(W.state); W.state = nullptr; W.state_bytes = 0; }
+                POA_CHECK(hipMalloc((void **)&W.state, ns * state_size));
+                W.state_bytes = ns * state_size;
+            }
+            if (W.classic && want > 0) {  // (memory the classic pool holds is memory the segments cannot have)
+                size_t free_b = 0, total_b = 0;
+                POA_CHECK(hipMemGetInfo(&free_b, &total_b));
+                uint64_t have;
+                { std::lock_guard<std::mutex> lk(W.mu); have = W.pool_size; }
+                if (have < want && free_b < want - have + (8ull << 30)) { (void)hipFree(W.classic); W.classic = nullptr; W.classic_size = 0; }
+            }
+            W.seg_bytes = std::min<uint64_t>(1ull << POA_SEG_LOG2, std::max<uint64_t>(want, 16 * POA_CHUNK));
+            if (const char *e = getenv("VGA_POOL_SEG")) W.seg_bytes = std::max<uint64_t>(16 * POA_CHUNK, strtoull(e, nullptr, 10) & ~(POA_CHUNK - 1));
+            W.seg_bytes = std::min<uint64_t>(W.seg_bytes, 1ull << POA_SEG_LOG2);  // (chunks are numbered segment << 12 | chunk in segment)
+            W.request(want);
+            const uint64_t got = W.wait_for(std::min<uint64_t>(want, W.seg_bytes));
+            if (got >= 16 * POA_CHUNK) {
+                const uint32_t max_chunks = (uint32_t)(POA_MAX_SEGS * (1ull << (POA_SEG_LOG2 - 20)));
+                POA_CHECK(W.d_head.reserve(POA_LISTS * POA_LIST_STRIDE + 16));
+                POA_CHECK(W.d_next_chunk.reserve(max_chunks));
+                POA_CHECK(W.d_slot_flag.reserve(16ull * (uint64_t)ctx->n_cu + 64));
+                POA_CHECK(W.h_seg_base.reserve(POA_MAX_SEGS));
+                POA_CHECK(W.d_seg_base.reserve(POA_MAX_SEGS));
+                if (!W.add_stream) {
+                    POA_CHECK(hipStreamCreateWithFlags(&W.add_stream, hipStreamNonBlocking));
+                    POA_CHECK(W.reset_lists());
+                }
+                POA_CHECK(hipMemset(W.d_slot_flag.p, 0, ns * sizeof(uint32_t)));
+                n_arenas = (uint32_t)ns;
+                CP.head = W.d_head.p; CP.next = W.d_next_chunk.p; CP.seg_base = W.d_seg_base.p;
+                CP.cps_log2 = POA_SEG_LOG2 - 20; CP.n_slots = n_arenas; CP.state_base = W.state; CP.state_size = state_size;
+                CP.slot_flag = W.d_slot_flag.p; CP.stats = W.d_head.p + POA_LISTS * POA_LIST_STRIDE;
+            }
         }
     }
-    if (tr.on) fprintf(stderr, "[vga-trace] poa: pool %.1f GB, %u arenas of %.1f MB\n", (double)W.pool_size / 1e9, n_arenas, (double)arena_size / 1e6);
+    // new segments' chunks join the free list (called before every launch; a tiny kernel on a stream of its own)
+    auto list_new_segments = [&]() -> hipError_t {
+        std::vector<poa_ws::seg_t> fresh;
+        {
+            std::lock_guard<std::mutex> lk(W.mu);
+            for (size_t k = W.segs_listed; k < W.segs.size(); k++) fresh.push_back(W.segs[k]);
+        }
+        for (const poa_ws::seg_t &g : fresh) {
+            const uint32_t first = (uint32_t)W.segs_listed << (POA_SEG_LOG2 - 20), cnt = (uint32_t)(g.size >> 20);
+            W.h_seg_base.p[W.segs_listed] = (uint64_t)g.p;
+            (void)hipMemcpyAsync(W.d_seg_base.p + W.segs_listed, W.h_seg_base.p + W.segs_listed, sizeof(uint64_t), hipMemcpyHostToDevice, W.add_stream);
+            hipLaunchKernelGGL(k_poa_chunks_add, dim3(1), dim3(64), 0, W.add_stream, CP, first, cnt);
+            W.segs_listed++;
+            W.chunks_listed += cnt;
+        }
+        hipError_t e = fresh.empty() ? hipSuccess : hipStreamSynchronize(W.add_stream);
+        // requests that found the list empty: the pool is short of what the resident workgroups need -- more segments
+        if (e == hipSuccess && ++W.polls % 64 == 0) {
+            unsigned long long empties = 0;
+            e = hipMemcpyAsync(&empties, W.d_head.p + POA_LISTS * POA_LIST_STRIDE, sizeof empties, hipMemcpyDeviceToHost, W.add_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(W.add_stream);
+            if (e == hipSuccess && empties > W.empties_seen) {
+                W.empties_seen = empties;
+                uint64_t ps; { std::lock_guard<std::mutex> lk(W.mu); ps = std::max(W.pool_size, W.grow_target); }
+                const uint64_t more = std::min<uint64_t>(ps + ps / 2 + (4ull << 30), avail_pool);
+                if (more > ps) W.request(more);
+            }
+        }
+        return e;
+    };
+    // ---- the classic pool: one contiguous piece, cut into a part per slot; allocated when a classic launch is first needed
+    uint64_t half_pool = 0;
+    double classic_need = probe_mean * (double)n;  // estimated bytes of the problems that will run in classic mode (the whole call, or what chunk mode handed back)
+    auto ensure_classic = [&]() -> int {
+        if (half_pool) return VGA_OK;
+        const double want_d = classic_need * W.pool_scale * 1.3 + std::min<double>((double)n, classic_need / std::max(1.0, probe_mean) + 64.0) * 3.0 * (double)POA_CHUNK;
+        const uint64_t want = (uint64_t)want_d + 64 * POA_CHUNK;
+        uint64_t target = std::min(std::max<uint64_t>(2 * want, n_arenas ? 1ull << 30 : 8ull << 30), avail_pool) & ~(POA_CHUNK - 1);
+        if (W.classic_size < std::min<uint64_t>(want, target)) {
+            if (W.classic) { (void)hipFree(W.classic); W.classic = nullptr; W.classic_size = 0; }
+            if (target < 64 * POA_CHUNK) return vga_set_error(ctx, VGA_ERR_NOMEM, "only %llu bytes of HBM for the traceback pool", (unsigned long long)target);
+            // the chunk segments give way (no chunk-mode launch is in flight when a classic one starts)
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            if (free_b < target + (4ull << 30)) {
+                W.stop_grower();
+                std::lock_guard<std::mutex> lk(W.mu);
+                for (auto &g : W.segs) (void)hipFree(g.p);
+                W.segs.clear(); W.pool_size = 0; W.segs_listed = 0; W.chunks_listed = 0; W.empties_seen = 0;
+                if (W.d_head.p) (void)W.reset_lists();
+                (void)hipMemGetInfo(&free_b, &total_b);
+                target = std::min<uint64_t>(target, free_b > (4ull << 30) ? (free_b - (4ull << 30)) & ~(POA_CHUNK - 1) : target);
+            }
+            const hipError_t e = hipMalloc((void **)&W.classic, target);
+            if (e != hipSuccess) return vga_set_error(ctx, VGA_ERR_NOMEM, "hipMalloc of the %llu byte traceback pool failed: %s", (unsigned long long)target, hipGetErrorString(e));
+            W.classic_size = target;
+        }
+        half_pool = (W.classic_size / (uint64_t)n_slots) & ~(POA_CHUNK - 1);
+        return VGA_OK;
+    };
+    if (!n_arenas) { const int rc = ensure_classic(); if (rc != VGA_OK) return rc; }
+    tr.mark("pool");
+    if (tr.on) {
+        uint64_t ps; { std::lock_guard<std::mutex> lk(W.mu); ps = W.pool_size; }
+        fprintf(stderr, "[vga-trace] poa: %s; chunk segments so far %.1f GB, %u state regions of %.2f MB, classic pool %.1f GB\n", n_arenas ? "chunk-pool mode" : "classic mode",
+                (double)ps / 1e9, n_arenas, (double)state_size / 1e6, (double)W.classic_size / 1e9);
+    }
 
     poa_dev_params P;
     P.match = params->match; P.mismatch = params->mismatch; P.o1 = params->gap_open1; P.e1 = params->gap_ext1;
@@ -479,7 +657,12 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     auto launch = [&](uint64_t i0, uint64_t cap, int slot, bool general, bool arena) -> sub_t {
         hipStream_t st = sarr[slot];  // shadows the context's stream inside this lambda
         poa_slot &S = W.slot[slot];
-        uint8_t *pool_base = arena ? W.pool : W.pool + (uint64_t)slot * half_pool;
+        if (!arena) {
+            const int rcc = ensure_classic();
+            if (rcc != VGA_OK) { dev_failed = true; dev_rc = rcc; return {i0, i0, 0.0, slot, 0}; }
+        }
+        if (arena && launch_err == hipSuccess) launch_err = list_new_segments();
+        uint8_t *pool_base = arena ? nullptr : W.classic + (uint64_t)slot * half_pool;
         const double budget = (double)half_pool * 0.92;
         double used_est = 0, raw_est = 0, cells_est = 0;
         uint64_t i1 = i0;
@@ -498,7 +681,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             if (feed.klass && i1 > i0 && feed.klass[order[i1]] != feed.klass[order[i0]]) break;
             used_est += e;
             // (arena mode: problems that are sent on to the classic pass take no arena and do not count)
-            if (!arena || e * 1.1 <= (double)arena_size) raw_est += est[order[i1]];
+            raw_est += est[order[i1]];
             cells_est += (double)G[order[i1]].N * estw[order[i1]];
             i1++;
         }
@@ -519,7 +702,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             pb.node0 = tot_nodes; pb.pred0 = tot_preds; pb.sink0 = tot_sink; pb.q0 = tot_q; pb.ops0 = tot_ops; pb.row0 = tot_rows;
             pb.seq0 = tot_seq;
             pb.n_sink = g.n_sinks; pb.qlen = g.qlen; pb.N = g.N; pb.n_nodes = g.n_ntab; pb.ring_rows = g.life + 1;
-            pb.flags = arena && (est[p] * W.pool_scale + 3.0 * (double)POA_CHUNK) * 1.1 > (double)arena_size ? 1u : 0u;
+            pb.flags = 0u;  // (bit 0: not for the chunk pool -- every problem of a chunk-mode call fits it by construction)
             pb.pad = 0;
             pb.w = params->wb < 0 ? g.qlen : (uint32_t)((int64_t)params->wb + (int64_t)(params->wf * (double)g.qlen));
             tot_nodes += g.n_ntab;
@@ -539,6 +722,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             chk(S.h_preds.reserve(tot_preds + 1)); chk(S.h_sink.reserve(tot_sink + 1)); chk(S.h_q.reserve(tot_q + 1));
         }
         chk(O.h_ops.reserve(tot_ops)); chk(O.h_orow.reserve(tot_ops)); chk(O.h_outs.reserve(nb));
+        if (feed.dev) chk(O.h_seq.reserve(tot_seq + 4));
         chk(S.d_probs.reserve(nb)); chk(S.d_ntab.reserve(tot_nodes)); chk(S.d_seq32.reserve(tot_seq / 4 + 1));
         chk(S.d_preds.reserve(tot_preds + 1)); chk(S.d_sink.reserve(tot_sink + 1)); chk(S.d_q.reserve(tot_q + 1));
         chk(S.d_rows.reserve(tot_rows)); chk(S.d_outs.reserve(nb)); chk(S.d_ops.reserve(tot_ops)); chk(S.d_orow.reserve(tot_ops));
@@ -672,13 +856,14 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             sub_t4 = t4;
             sub_t5 = t5;
             if (t4) {
+                poa_chunk_pool cp_arg = CP;
+                if (!arena) cp_arg.n_slots = 0;
                 const poa_t5_args t5a = {S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_rows.p, pool_base, W.d_next.p + slot, half_pool,
-                                         S.d_outs.p, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr), W.d_arena_ctr.p,
-                                         W.d_arena_flag.p, arena_size, (arena ? n_arenas : 0u), lds_cols, hg_cols, win_mask, P};
+                                         S.d_outs.p, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr), cp_arg, lds_cols, hg_cols, win_mask, P};
                 (void)t5a;
 #define POA_T4_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, P, S.d_rows.p, pool_base, W.d_next.p + slot, half_pool,   \
                     S.d_outs.p, lds_cols, hg_cols, win_mask, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr),       \
-                    (arena ? n_arenas : 0u), arena_size, W.d_arena_ctr.p, W.d_arena_flag.p
+                    0u, (uint64_t)0, (unsigned long long *)nullptr, (uint32_t *)nullptr
 #define POA_T4_LAUNCH(T)                                                                                                     \
     case T:                                                                                                                  \
         if (t5 && def_pen) {                                                                                                 \
@@ -734,6 +919,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         chk(hipMemcpyAsync(W.h_next.p + slot, W.d_next.p + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(O.h_ops.p, S.d_ops.p, tot_ops, hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(O.h_orow.p, S.d_orow.p, tot_ops * 4, hipMemcpyDeviceToHost, st));
+        // (device store: the cs strings need the graph bases of the aligned rows -- the gathered node sequences come back too,
+        // 17 KB per problem, instead of a handle lookup per aligned base)
+        if (feed.dev) chk(hipMemcpyAsync(O.h_seq.p, S.d_seq32.p, tot_seq, hipMemcpyDeviceToHost, st));
         return {i0, i1, raw_est, slot, oset, false, arena};
     };
     // host: CIGAR / cs / node path of one problem from the raw op stream (reverse order on the device)
@@ -752,56 +940,67 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         const uint8_t *po = S.h_ops.p + pb.ops0;
         const uint32_t *pr = S.h_orow.p + pb.ops0;
         const char *q = views[p].query;
-        // base of graph row r (rows ascend along the path): bases[r - 1] of the host graph, or -- device store -- the
-        // index sequence via the node the row belongs to
-        const char *bases = feed.dev ? nullptr : views[p].nodes + views[p].node_off[0];
+        // base of graph row r: bases[r - 1] -- the node strings of a host graph, or (device store) the sub-batch's gathered
+        // node sequences, which came back with the operations
+        const char *bases = feed.dev ? S.h_seq.p + pb.seq0 : views[p].nodes + views[p].node_off[0];
         const uint32_t *frow = g.first_row_p;
         const size_t nv = (size_t)g.n_ntab - 1;
-        size_t vcur = 0;
-        auto base_of = [&](uint32_t r) -> char {
-            if (bases) return bases[r - 1];
-            while (vcur + 1 < nv && frow[vcur + 1] <= r) vcur++;
-            return feed.row_base(p, (uint32_t)vcur, r - frow[vcur]);
-        };
         const uint32_t nops = ho.nops;
+        // one pass over the operations (stored sink -> source), writing through raw pointers into buffers of the largest
+        // possible size: 3 characters per operation for cs ("*ac"), a run of one per operation for the CIGAR ("1M")
         std::string &cg = it.cigar, &cs = it.cs;
-        cs = "cs:Z:";
-        cg.reserve(nops / 2 + 16);
-        cs.reserve(nops / 2 + 16);
-        it.rows.reserve(g.N < nops ? g.N : nops);
+        cs.resize(5 + 3 * (size_t)nops + 24);
+        cg.resize(2 * (size_t)nops + 24);
+        it.rows.resize(nops);
+        char *c = &cs[0], *d = &cg[0];
+        uint32_t *rowp = it.rows.data();
+        memcpy(c, "cs:Z:", 5);
+        c += 5;
+        auto put_u = [](char *&w, uint64_t v) {
+            char t[24];
+            int k = 0;
+            do { t[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+            while (k) *w++ = t[--k];
+        };
         uint64_t eq_run = 0, aligned = 0;
-        uint32_t qi = 0;
+        uint32_t qi = 0, n_rows = 0;
         uint32_t t2 = nops;
         while (t2 > 0) {
             const uint8_t op = po[t2 - 1];
-            uint32_t u = t2, run = 0;
-            while (u > 0 && po[u - 1] == op) { u--; run++; }
-            append_u(cg, run);
-            cg.push_back(op == 0 ? 'M' : (op == 1 ? 'I' : 'D'));
-            if (op != 0 && eq_run) { cs.push_back(':'); append_u(cs, eq_run); eq_run = 0; }
-            if (op == 1) cs.push_back('+');
-            if (op == 2) cs.push_back('-');
-            for (uint32_t x = t2; x > u; x--) {
-                const uint32_t idx = x - 1;
-                if (op == 0) {
-                    const char gb = base_of(pr[idx]), qb = q[qi++];
-                    aligned++;
+            uint32_t u = t2 - 1;
+            while (u > 0 && po[u - 1] == op) u--;
+            put_u(d, t2 - u);
+            *d++ = op == 0 ? 'M' : (op == 1 ? 'I' : 'D');
+            if (op != 0 && eq_run) { *c++ = ':'; put_u(c, eq_run); eq_run = 0; }
+            if (op == 0) {
+                for (uint32_t x = t2; x > u; x--) {
+                    const uint32_t r = pr[x - 1];
+                    const char gb = bases[r - 1], qb = q[qi++];
+                    rowp[n_rows++] = r;
                     if (gb == qb) eq_run++;
                     else {
-                        if (eq_run) { cs.push_back(':'); append_u(cs, eq_run); eq_run = 0; }
-                        cs.push_back('*'); cs.push_back(lower(gb)); cs.push_back(lower(qb));
+                        if (eq_run) { *c++ = ':'; put_u(c, eq_run); eq_run = 0; }
+                        *c++ = '*'; *c++ = lower(gb); *c++ = lower(qb);
                     }
-                    it.rows.push_back(pr[idx]);
-                } else if (op == 1) {
-                    cs.push_back(lower(q[qi++]));
-                } else {
-                    cs.push_back(lower(base_of(pr[idx])));
-                    it.rows.push_back(pr[idx]);
+                }
+                aligned += t2 - u;
+            } else if (op == 1) {
+                *c++ = '+';
+                for (uint32_t x = t2; x > u; x--) *c++ = lower(q[qi++]);
+            } else {
+                *c++ = '-';
+                for (uint32_t x = t2; x > u; x--) {
+                    const uint32_t r = pr[x - 1];
+                    rowp[n_rows++] = r;
+                    *c++ = lower(bases[r - 1]);
                 }
             }
             t2 = u;
         }
-        if (eq_run) { cs.push_back(':'); append_u(cs, eq_run); }
+        if (eq_run) { *c++ = ':'; put_u(c, eq_run); }
+        cs.resize((size_t)(c - &cs[0]));
+        cg.resize((size_t)(d - &cg[0]));
+        it.rows.resize(n_rows);
         it.aligned = (uint32_t)aligned;
         // rows ascend along the path: merge-walk the node table to label them
         it.gnodes.resize(it.rows.size());
@@ -824,7 +1023,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     std::vector<seg_t> todo;  // used as a stack of [begin, end) ranges of launch positions, front = back()
     todo.push_back({0, n, false, n_arenas != 0});
     std::vector<uint32_t> retry;  // problems a specialised DP kernel handed back (POA_ST_RETRY): re-run with the general one
-    std::vector<uint32_t> too_big;  // problems that did not fit an arena: classic mode once the arena launches are done
+    std::vector<uint32_t> too_big;  // problems chunk mode gave up on twice: classic mode once the chunk-mode launches are done
+    std::vector<uint32_t> again;    // ... once: they run again in chunk mode when the others are through (the pool has grown, fewer compete)
+    std::vector<uint8_t> gave_up(n, 0);
     std::vector<sub_t> inflight;
     bool slot_busy[POA_SLOTS] = {};
     uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
@@ -859,7 +1060,16 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                     const hipError_t qe = hipStreamQuery(sarr[inflight[q].slot]);
                     if (qe != hipErrorNotReady) { pick = q; found = true; }  // finished (or failed: the synchronize below reports it)
                 }
-                if (!found) std::this_thread::sleep_for(std::chrono::microseconds(100));
+                if (!found) {
+                    if (n_arenas && !getenv("VGA_POOL_NOPOLL")) (void)list_new_segments();  // (segments the grower has finished meanwhile: their chunks join the free list)
+                    std::this_thread::sleep_for(std::chrono::microseconds(100));
+                }
+            }
+        }
+        if (n_arenas && inflight.size() == 1) {
+            while (!getenv("VGA_POOL_NOPOLL") && hipStreamQuery(sarr[inflight[0].slot]) == hipErrorNotReady) {
+                (void)list_new_segments();
+                std::this_thread::sleep_for(std::chrono::microseconds(200));
             }
         }
         const sub_t cur = inflight[pick];
@@ -873,8 +1083,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         bool pool_fail = false;
         for (uint64_t i = cur.i0; i < cur.i1; i++)
             if (S.h_outs.p[i - cur.i0].status == POA_ST_POOL) {
-                if (cur.arena) too_big.push_back(order[i]);
-                else pool_fail = true;
+                if (cur.arena) {
+                    if (gave_up[order[i]]++ == 0) again.push_back(order[i]);
+                    else too_big.push_back(order[i]);
+                } else pool_fail = true;
             }
         if (pool_fail) {
             slot_busy[cur.slot] = false;
@@ -954,10 +1166,19 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             retry.clear();
             todo.push_back({a, order.size(), true, n_arenas != 0});
         }
+        if (todo.empty() && inflight.empty() && !again.empty()) {
+            const uint64_t a = order.size();
+            for (uint32_t p : again) order.push_back(p);
+            if (tr.on) fprintf(stderr, "[vga-trace] poa: %zu problems gave up waiting for chunks: they run again\n", again.size());
+            again.clear();
+            todo.push_back({a, order.size(), cur.general, true});
+        }
         if (todo.empty() && inflight.empty() && !too_big.empty()) {
+            classic_need = 0;
+            for (uint32_t p : too_big) classic_need += est[p];
             const uint64_t a = order.size();
             for (uint32_t p : too_big) order.push_back(p);
-            if (tr.on) fprintf(stderr, "[vga-trace] poa: %zu problems did not fit an arena of %.1f MB: classic pass\n", too_big.size(), (double)arena_size / 1e6);
+            if (tr.on) fprintf(stderr, "[vga-trace] poa: %zu problems gave up waiting for chunks (or need more contiguous state than a region holds): classic pass\n", too_big.size());
             too_big.clear();
             todo.push_back({a, order.size(), cur.general, false});
         }
@@ -988,6 +1209,13 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     if (dev_failed) return dev_rc;  // (sg_prepare_rest has set the message)
     vga_timer_end(ctx, t_total);
     tr.mark("dp + traceback + cigar (pipelined sub-batches)");
+    if (tr.on && n_arenas) {
+        unsigned long long empties = 0;
+        (void)hipMemcpy(&empties, W.d_head.p + POA_LISTS * POA_LIST_STRIDE, sizeof empties, hipMemcpyDeviceToHost);
+        uint64_t ps; { std::lock_guard<std::mutex> lk(W.mu); ps = W.pool_size; }
+        fprintf(stderr, "[vga-trace] poa: chunk pool %.1f GB in %zu segments (%u chunks listed); since the context began %llu requests found every free list empty\n",
+                (double)ps / 1e9, W.segs_listed, W.chunks_listed, empties);
+    }
     if (rc_final != VGA_OK)
         return vga_set_error(ctx, rc_final, "a single POA problem does not fit the %llu byte traceback pool",
                              (unsigned long long)W.pool_size);

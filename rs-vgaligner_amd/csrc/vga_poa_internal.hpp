@@ -41,15 +41,14 @@ struct poa_timing {
 // = bigger) fixes the launch order up front.  Without `prepare` every view is complete and the order is by footprint.
 // With `dev` set the graphs never exist on the host: the node tables, predecessor lists, sinks and bases of all problems
 // already sit in the device store sg_prepare filled (vga_subgraph.hip) and are gathered into a sub-batch's buffers device to
-// device; the queries come from the batch's device copy of the reads.  `row_base(p, node, off)` then gives the base of a
-// node's row for the cs strings (the index sequence, via the problem's handle list).
+// device; the queries come from the batch's device copy of the reads (the gathered node sequences come back with a sub-batch's
+// results for the cs strings).
 struct poa_feed {
     std::vector<poa_view> views;
     std::function<void(const uint32_t *ids, uint64_t cnt)> prepare;
     const double *proxy = nullptr;
     const sg_store *dev = nullptr;
     std::function<int()> dev_rest;  // prepares the store's second part (problems >= dev->split); called once, when they are first needed
-    std::function<char(uint64_t p, uint32_t node, uint32_t off)> row_base;
     // optional: the launch order itself (n problem indices; poa_run then does not sort by proxy) and a class per problem
     // (1 = very long: such problems are launched apart, with the largest workgroup and window)
     const uint32_t *order = nullptr;

@@ -91,6 +91,88 @@ struct poa_dev_params {
 #endif
 #define POA_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+__device__ __forceinline__ uint64_t poa_uniform_u64(uint64_t v)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+// The traceback pool of k_poa_dp_t5 (vga_poa.hip: poa_ws owns it).  Direction rows -- nine tenths of a problem's footprint, and
+// unknown in size until the rows have been computed, because the band is adaptive -- come out of 1 MiB CHUNKS that a
+// workgroup pops from a device-wide lock-free free list when it needs one and pushes back, all at once, when its traceback
+// is done: what the pool has to hold is what the resident workgroups have written SO FAR, not a worst-case arena for each
+// (rounds 1-2: 2 000 arenas of 128 MB = 257 GB of HBM for problems that use 20-55 MB; allocating and freeing that much
+// dominated a 10 000-read run of the command line tool).  The chunks live in SEGMENTS that the host allocates on a thread
+// of its own while launches already run (a chunk's address: seg_base[chunk >> cps_log2] + ((chunk & mask) << 20), the table
+// in device memory, an entry written before its chunks are listed).  What must be contiguous -- the value-row ring, the two wide-row scratch rows, kept value rows --
+// sits in a small fixed STATE region per resident workgroup, taken like an arena before (flag 0 -> 1).
+// Offsets stored in the row records are absolute device addresses in this mode (pool base 0).
+#define POA_NIL 0xFFFFFFFFu
+#define POA_LISTS 64        // the free list is sharded: workgroups of a launch start together and run in step, so they ask for
+#define POA_LIST_STRIDE 16  // chunks at the same moments -- one list head would serialise 2 000 compare-and-swap loops
+struct poa_chunk_pool {
+    unsigned long long *head;    // [POA_LISTS * POA_LIST_STRIDE] free lists: change counter << 32 | first free chunk (POA_NIL: none)
+    uint32_t *next;              // per chunk: the next chunk of the list it is in (a free list, or its owner's)
+    const uint64_t *seg_base;    // device address of every segment
+    uint32_t cps_log2;           // chunks per segment, log2
+    uint32_t n_slots;            // state regions (0: classic mode, no chunk pool)
+    uint8_t *state_base;         // n_slots regions of state_size bytes
+    uint64_t state_size;
+    uint32_t *slot_flag;         // 0 free / 1 taken
+    unsigned long long *stats;   // [0] requests that found every list empty (the host adds segments when it grows)
+};
+__device__ __forceinline__ uint64_t poa_chunk_addr(const poa_chunk_pool &C, uint32_t idx)
+{
+    return C.seg_base[idx >> C.cps_log2] + ((uint64_t)(idx & ((1u << C.cps_log2) - 1u)) << 20);
+}
+// one thread: pop a chunk, starting at this workgroup's home list and going round; waits (bounded, ~0.1 s) while all lists
+// are empty -- chunks come back as other workgroups finish, and new segments arrive from the host
+__device__ __forceinline__ uint32_t poa_chunk_pop(const poa_chunk_pool &C, uint32_t home)
+{
+    for (uint32_t round = 0; round < (1u << 15); round++) {
+        for (uint32_t k = 0; k < POA_LISTS; k++) {
+            unsigned long long *hd = C.head + (size_t)((home + k) % POA_LISTS) * POA_LIST_STRIDE;
+            for (;;) {
+                unsigned long long h = __hip_atomic_load(hd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t idx = (uint32_t)h;
+                if (idx == POA_NIL) break;
+                const uint32_t nx = __hip_atomic_load(C.next + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (atomicCAS(hd, h, ((h >> 32) + 1ull) << 32 | nx) == h) return idx;
+            }
+        }
+        if (round == 0) (void)atomicAdd(C.stats, 1ull);
+        __builtin_amdgcn_s_sleep(127);
+    }
+    return POA_NIL;
+}
+// one thread: push the list first -> ... -> last (linked through C.next) onto free list `home` in one step
+__device__ __forceinline__ void poa_chunk_push(const poa_chunk_pool &C, uint32_t home, uint32_t first, uint32_t last)
+{
+    unsigned long long *hd = C.head + (size_t)(home % POA_LISTS) * POA_LIST_STRIDE;
+    for (;;) {
+        unsigned long long h = __hip_atomic_load(hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(C.next + last, (uint32_t)h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (atomicCAS(hd, h, ((h >> 32) + 1ull) << 32 | first) == h) return;
+    }
+}
+// a new segment's chunks [first, first + count): dealt round the free lists (thread l builds and pushes list l's share)
+__global__ void k_poa_chunks_add(poa_chunk_pool C, uint32_t first, uint32_t count)
+{
+    const uint32_t l = threadIdx.x;
+    if (blockIdx.x != 0 || l >= POA_LISTS || l >= count) return;
+    uint32_t last = first + l;
+    for (uint32_t i = first + l; i + POA_LISTS < first + count; i += POA_LISTS) { C.next[i] = i + POA_LISTS; last = i + POA_LISTS; }
+    poa_chunk_push(C, l, first + l, last);
+}
+__device__ __forceinline__ int poa_slot_acquire(uint32_t *flag, uint32_t n, uint32_t block)
+{
+    uint32_t a = (uint32_t)(((uint64_t)block * 2654435761ull) % n);
+    for (uint32_t tries = 0; tries < (1u << 24); tries++) {
+        if (atomicCAS(&flag[a], 0u, 1u) == 0u) return (int)a;
+        a = a + 1 == n ? 0 : a + 1;
+        if ((tries & 15u) == 15u) __builtin_amdgcn_s_sleep(64);
+    }
+    return -1;
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int poa_dpp(int old, int v)
 {

@@ -53,10 +53,8 @@ struct poa_t5_args {
     poa_out *outs;
     uint8_t *tb_ops;
     uint32_t *tb_orow;
-    unsigned long long *arena_ctr;
-    uint32_t *arena_flag;
-    uint64_t arena_size;
-    uint32_t n_arenas, lds_cols, hg_cols, win_mask;
+    poa_chunk_pool cp;  // cp.n_slots != 0: direction rows out of the chunk pool, the rest out of a state region
+    uint32_t lds_cols, hg_cols, win_mask;
     poa_dev_params P;
 };
 // a scalar of its own: cuts a uniform value loose from the (wide) load that produced it
@@ -83,10 +81,8 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
     uint8_t *pool_arg = A.pool;
     unsigned long long *pool_next_arg = A.pool_next;
     const uint64_t pool_size_arg = A.pool_size;
-    const uint32_t lds_cols = t5_own(A.lds_cols), hg_cols = t5_own(A.hg_cols), win_mask = t5_own(A.win_mask), n_arenas = A.n_arenas;
-    const uint64_t arena_size = A.arena_size;
-    unsigned long long *arena_ctr = A.arena_ctr;
-    uint32_t *arena_flag = A.arena_flag;
+    const uint32_t lds_cols = t5_own(A.lds_cols), hg_cols = t5_own(A.hg_cols), win_mask = t5_own(A.win_mask);
+    const bool chunked = A.cp.n_slots != 0;
     struct { int match, mismatch, o1, e1, o2, e2, banded; } P = {t5_own(A.P.match), t5_own(A.P.mismatch), A.P.o1, A.P.e1, A.P.o2, A.P.e2, t5_own(A.P.banded)};
     constexpr int NW = NT / 64;
     constexpr int STEP = NT * 4;
@@ -113,22 +109,19 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
     poa_row *R = rows + t5_own(pb.row0);
     const uint32_t n_nodes = t5_own(pb.n_nodes), ring_rows = t5_own(pb.ring_rows);
 
-    // ---- pool: classic (chunks of the launch's segment) or arena mode, as in k_poa_dp_t4
+    // ---- pool: classic (bump allocation out of the launch's segment, offsets relative to it) or the chunk pool
+    // (vga_poa_kernels.hpp: a state region for what must be contiguous, 1 MiB chunks for the direction rows; offsets are
+    // device addresses, pool base 0)
     uint8_t *pool = pool_arg;
     unsigned long long *pool_next = pool_next_arg;
     uint64_t pool_size = pool_size_arg;
-    uint32_t arena = 0;
-    if (n_arenas) {
+    uint32_t state_slot = 0;
+    uint64_t state_lo = 0, state_hi = 0;
+    if (chunked) {
         int got = -1;
         if (!(pb.flags & 1u)) {
             if (tid == 0) {
-                uint32_t a = (uint32_t)(((uint64_t)blockIdx.x * 2654435761ull) % n_arenas);
-                for (uint32_t tries = 0; tries < (1u << 24); tries++) {
-                    if (atomicCAS(&arena_flag[a], 0u, 1u) == 0u) { got = (int)a; break; }
-                    a = a + 1 == n_arenas ? 0 : a + 1;
-                    if ((tries & 15u) == 15u) __builtin_amdgcn_s_sleep(64);
-                }
-                if (got >= 0) (void)atomicExch(&arena_ctr[got], 0ull);
+                got = poa_slot_acquire(A.cp.slot_flag, A.cp.n_slots, blockIdx.x);
                 sSink[1] = got;
             }
             __syncthreads();
@@ -143,10 +136,10 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
             return;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        arena = (uint32_t)got;
-        pool = pool_arg + (uint64_t)arena * arena_size;
-        pool_next = arena_ctr + arena;
-        pool_size = arena_size;
+        state_slot = (uint32_t)got;
+        pool = nullptr;
+        state_lo = (uint64_t)A.cp.state_base + (uint64_t)state_slot * A.cp.state_size;
+        state_hi = state_lo + A.cp.state_size;
     }
     pool_size = t5_own(pool_size);
 
@@ -168,17 +161,42 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
     // every wave reaches this branch in the same row (the condition only depends on replicated state), `slot` keeps the
     // two requests of one row apart.
     bool failed = false;
+    uint32_t own_head = POA_NIL, own_tail = POA_NIL, own_chunks = 0;  // chunk pool: the chunks this workgroup holds (a list through cp.next)
     auto alloc = [&](uint64_t &cur, uint64_t &end, uint64_t bytes, int slot) -> uint64_t {
         bytes = (bytes + 15ull) & ~15ull;
         if (__builtin_expect(cur + bytes > end, 0)) {
-            const uint64_t need = bytes > POA_CHUNK ? (bytes + POA_CHUNK - 1) & ~(POA_CHUNK - 1) : POA_CHUNK;
-            if (tid == 0) sChunk[slot] = atomicAdd(pool_next, (unsigned long long)need);
-            __syncthreads();
-            const uint64_t b = t5_uniform64(sChunk[slot]);
-            __syncthreads();  // (rare path: the slot may be written again as soon as every wave has read it)
-            if (b + need > pool_size) failed = true;
-            cur = b;
-            end = b + need;
+            if (chunked) {
+                if (slot == 0 && bytes <= POA_CHUNK) {
+                    // direction rows: the next chunk from the free list, chained in front of the ones this workgroup holds
+                    if (tid == 0) {
+                        const uint32_t idx = poa_chunk_pop(A.cp, blockIdx.x);
+                        if (idx != POA_NIL) __hip_atomic_store(A.cp.next + idx, own_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sChunk[0] = idx;
+                    }
+                    __syncthreads();
+                    const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sChunk[0]);
+                    __syncthreads();
+                    if (idx == POA_NIL) failed = true;
+                    else {
+                        own_head = idx;
+                        if (own_tail == POA_NIL) own_tail = idx;
+                        own_chunks++;
+                        cur = poa_uniform_u64(poa_chunk_addr(A.cp, idx));
+                        end = cur + POA_CHUNK;
+                    }
+                } else
+                    failed = true;  // (the state region is exhausted, or a row larger than a chunk: the classic pass takes the problem)
+                if (failed) return cur;
+            } else {
+                const uint64_t need = bytes > POA_CHUNK ? (bytes + POA_CHUNK - 1) & ~(POA_CHUNK - 1) : POA_CHUNK;
+                if (tid == 0) sChunk[slot] = atomicAdd(pool_next, (unsigned long long)need);
+                __syncthreads();
+                const uint64_t b = t5_uniform64(sChunk[slot]);
+                __syncthreads();  // (rare path: the slot may be written again as soon as every wave has read it)
+                if (b + need > pool_size) failed = true;
+                cur = b;
+                end = b + need;
+            }
         }
         const uint64_t r = cur;
         cur += bytes;
@@ -205,19 +223,23 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
     }
     const bool q_plain = __builtin_amdgcn_readfirstlane(__syncthreads_or(non_acgt)) == 0;
 
-    uint64_t dcur = 0, dend = 0, vcur = 0, vendp = 0, wide_scratch = 0, ring_base = 0;
+    uint64_t dcur = 0, dend = 0, vcur = state_lo, vendp = state_hi, wide_scratch = 0, ring_base = 0;
     uint32_t ring_head = 0;  // the slot the next node-end row takes
     uint32_t ring_size;      // bytes per slot of the ring: one worst-case row
     if (win_mask != 0xFFFFFFFFu) wide_scratch = alloc(vcur, vendp, 2ull * 6ull * lds_cols, 1);
     {
         const uint64_t maxrow = (6ull * (uint64_t)((qlen + 8) & ~3) + 15ull) & ~15ull;
-        const uint64_t rb = (maxrow * (uint64_t)ring_rows + POA_CHUNK - 1) & ~(POA_CHUNK - 1);
-        if (tid == 0) sChunk[2] = atomicAdd(pool_next, (unsigned long long)rb);
-        __syncthreads();
-        const uint64_t b = t5_uniform64(sChunk[2]);
-        if (b + rb > pool_size || rb >= (1ull << 32)) failed = true;
-        ring_base = b;
         ring_size = (uint32_t)maxrow;
+        if (chunked) {
+            ring_base = alloc(vcur, vendp, maxrow * (uint64_t)ring_rows, 1);  // (out of the state region)
+        } else {
+            const uint64_t rb = (maxrow * (uint64_t)ring_rows + POA_CHUNK - 1) & ~(POA_CHUNK - 1);
+            if (tid == 0) sChunk[2] = atomicAdd(pool_next, (unsigned long long)rb);
+            __syncthreads();
+            const uint64_t b = t5_uniform64(sChunk[2]);
+            if (b + rb > pool_size || rb >= (1ull << 32)) failed = true;
+            ring_base = b;
+        }
     }
     if (tid == 0) { sSink[2] = POA_NEG; sSink[3] = 0; }  // best sink value so far / its row + 1 (0: none yet)
     int prev_beg = 0, prev_end = -1;
@@ -358,7 +380,9 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
         const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u), 0);
         uint64_t voff = 0;
         if (last && !failed) {
-            if (r == 0 || (nt.z & 0x40000000u)) voff = alloc(vcur, vendp, 6ull * (uint64_t)W, 1);
+            // (a value row that outlives the ring: chunk-pool mode keeps it among the direction rows, whose chunks stay with the
+            // workgroup to the end; the state region only holds the ring and the scratch rows)
+            if (r == 0 || (nt.z & 0x40000000u)) voff = chunked ? alloc(dcur, dend, 6ull * (uint64_t)W, 0) : alloc(vcur, vendp, 6ull * (uint64_t)W, 1);
             else {
                 // fixed slots of one worst-case row: the rows of the last ring_rows node ends survive whatever their
                 // widths (a byte ring that wraps when a row does not fit can overwrite the row written two slots ago)
@@ -1013,17 +1037,17 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
         O.status = status;
     }
     if (E.tb_ops) {
-        uint8_t *pool_e = E.pool + (E.n_arenas ? (uint64_t)arena * E.arena_size : 0ull);
+        uint8_t *pool_e = E.cp.n_slots ? nullptr : E.pool;
         poa_traceback_wave<2>(*(tb_lds *)(smem + HDR), tid, pe, E.rows, E.preds, pool_e, O, E.tb_ops, E.tb_orow, 0, status, start_row);
     }
     if (tid == 0) {
         O.t_end = __builtin_amdgcn_s_memrealtime();
-        if (E.n_arenas) {
-            unsigned long long *ctr = E.arena_ctr + arena;
-            const unsigned long long used = atomicAdd(ctr, 0ull);
-            (void)atomicAdd(E.pool_next, used < E.arena_size ? used : (unsigned long long)E.arena_size);
+        if (E.cp.n_slots) {
+            // the chunks go back in one step, then the state region; what this problem took feeds the host's footprint scale
+            if (own_head != POA_NIL) poa_chunk_push(E.cp, blockIdx.x, own_head, own_tail);
+            (void)atomicAdd(E.pool_next, (unsigned long long)own_chunks * POA_CHUNK + (vcur - state_lo));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            (void)atomicExch(&E.arena_flag[arena], 0u);
+            (void)atomicExch(&E.cp.slot_flag[state_slot], 0u);
         }
     }
 }

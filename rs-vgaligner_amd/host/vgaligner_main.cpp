@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <unistd.h>
 
 using namespace vgh;
 
@@ -29,7 +30,7 @@ const Flag MAP_FLAGS[] = {{"-i", "--index", true, "index"}, {"-f", "--input-file
                           {"-P", "--validation-path", true, "validation-path"}, {"-p", "--poa-aligner", true, "poa-aligner"},
                           {"", "--out-prefix", true, "out-prefix"}, {"", "--n-threads", true, "n-threads"},
                           // not in the reference: --device one GPU, --devices a list (one context + host thread each; an id may
-                          // repeat; default: every visible GPU), --chunk-reads reads per batch (bounded memory; 0 = one batch)
+                          // repeat; --devices all: every visible GPU; default: --device 0), --chunk-reads reads per batch (bounded memory; 0 = one batch)
                           {"-d", "--device", true, "device"}, {"", "--devices", true, "devices"}, {"", "--chunk-reads", true, "chunk-reads"},
                           {"", "--poa-remain", true, "poa-remain"}};
 
@@ -109,10 +110,14 @@ int map_main(int argc, char **argv)
     }
     if (o.also_align && !m.count("graph")) throw Error("--also-align needs --graph (the reference unwraps it, map.rs:157)");
     bool exact = idx.size() >= 4 && idx.compare(idx.size() - 4, 4, ".idx") == 0;
+    trace_mark("start");
     Index ix = Index::load(exact ? idx : idx + ".idx");
+    trace_mark("index loaded");
     std::vector<QuerySequence> reads = read_seqs_from_file(in);
+    trace_mark("reads parsed");
     fprintf(stderr, "[vgaligner] Found %zu reads!\n", reads.size());
-    if (m.count("devices")) {
+    if (m.count("devices") && m["devices"] == "all") o.all_devices = true;
+    else if (m.count("devices")) {
         const std::string l = m["devices"];
         size_t p0 = 0;
         while (p0 <= l.size()) {
@@ -123,7 +128,8 @@ int map_main(int argc, char **argv)
             p0 = p1 + 1;
         }
         if (o.devices.empty()) throw Error("--devices needs a comma-separated list of GPU ids");
-    } else if (m.count("device")) o.devices.push_back(o.device);
+    }
+    o.leave_contexts = !getenv("VGA_NO_FAST_EXIT");
     o.chunk_reads = std::stoull(opt(m, "chunk-reads", "32768"));
     o.keep_text = o.write_console || o.also_validate;
     MapOutput out = map_reads_multi(ix, reads, o, prefix);
@@ -131,6 +137,12 @@ int map_main(int argc, char **argv)
     fprintf(stderr, "[vgaligner] Chaining took: %.0f ms\n", out.ms_map);
     if (o.also_align) fprintf(stderr, "[vgaligner] Alignment took: %.0f ms; Found %llu alignments!\n", out.ms_align, (unsigned long long)out.n_reads);
     if (o.write_console) fputs(o.also_align ? out.alignments_gaf.c_str() : out.chains_gaf.c_str(), stdout);
+    trace_mark("done");
+    if (o.leave_contexts) {  // the GAF files are closed; what is left is HBM the driver reclaims by itself
+        fflush(stdout);
+        fflush(stderr);
+        _exit(0);
+    }
     return 0;
 }
 
@@ -144,7 +156,7 @@ int main(int argc, char **argv)
         if (argc >= 2 && !strcmp(argv[1], "map")) return map_main(argc, argv);
         fprintf(stderr, "vgaligner 0.7 (MI355X build)\nUSAGE:\n  vgaligner index -i <graph.gfa> -k <K> [-o prefix] [-e 100] [-m 100]\n"
                         "  vgaligner map -i <index> -f <reads.fa|fq> -p abpoa [-o prefix] [-g 1000] [-a 3] [-b 1] [-D -G <graph.gfa>] [-C]\n"
-                        "                [--devices 0,1,...] [--chunk-reads 32768] [--poa-remain longest|first-edge]\n");
+                        "                [--device 0 | --devices 0,1,... | --devices all] [--chunk-reads 32768] [--poa-remain longest|first-edge]\n");
         return 2;
     } catch (const std::exception &e) {
         fprintf(stderr, "vgaligner: %s\n", e.what());

@@ -96,6 +96,8 @@ std::vector<QuerySequence> read_seqs_from_file(const std::string &filename);
 // ---- GAF --------------------------------------------------------------------------------------
 std::string gaf_placeholder(const QuerySequence &q);
 std::string gaf_from_chain(const Index &ix, const QuerySequence &q, const vga_map_result *m, uint64_t read, uint64_t chain);
+void gaf_from_chain_text(std::string &out, const Index &ix, const QuerySequence &q, const vga_map_result *m, uint64_t read, uint64_t chain,
+                         const char *path, uint64_t path_len);
 std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a, uint64_t read);
 // ValidationRecord::from_graph_and_alignment + to_string (src/validate.rs:36-102) from one alignments-GAF line
 std::string validation_record(const Index &ix, const std::string &gaf_line, const std::vector<QuerySequence> &reads);
@@ -117,14 +119,21 @@ struct MapOptions {
     // Multi-GPU / streaming (not in the reference, which is single-threaded): one context and one host thread per entry of
     // `devices` (an id may repeat: two contexts on one GPU), each mapping a contiguous slice of the reads balanced by bases, in
     // chunks of at most `chunk_reads` reads (0 = the whole slice at once) so that host and device memory stay bounded.
-    std::vector<int> devices;
+    std::vector<int> devices;            // empty: `device` alone (--devices all: every visible GPU)
+    bool all_devices = false;
     uint64_t chunk_reads = 32768;
+    // the caller is about to leave the process: the contexts are not torn down (freeing tens of GB of HBM takes the driver
+    // hundreds of milliseconds that a command line tool would only spend waiting)
+    bool leave_contexts = false;
     // false: map_reads_multi writes the GAF files chunk by chunk and returns no text (the CLI without -C / -v); true: the
     // whole GAF text comes back in MapOutput
     bool keep_text = true;
     bool also_validate = false;          // -v: write validation records (src/validate.rs:18-102, map.rs:186-208)
     std::string validation_path;         // -P
 };
+
+// VGA_TRACE=1: wall-clock marks of the driver's phases on stderr (since the first call)
+void trace_mark(const char *what);
 
 struct MapOutput {
     std::string chains_gaf, alignments_gaf, validation;

@@ -119,7 +119,7 @@ uint64_t vgh_plan_shards(const uint64_t *lengths, uint64_t n, uint32_t n_slots, 
     return plan.size();
 }
 
-// map_reads_multi over in-memory reads: one context per entry of devices[] (n_devices == 0: every visible GPU)
+// map_reads_multi over in-memory reads: one context per entry of devices[] (n_devices == 0: device 0)
 int vgh_map_reads_multi(void *h, uint64_t n, const char *const *names, const char *const *seqs, uint64_t max_gap,
                         uint64_t chain_min_n_anchors, int also_align, uint64_t align_best_n, const int *devices, uint32_t n_devices,
                         uint64_t chunk_reads, const char *out_prefix, char **chains_gaf, char **alignments_gaf, uint64_t *n_aligned,

@@ -19,6 +19,18 @@
 
 namespace vgh {
 
+void trace_mark(const char *what)
+{
+    static const bool on = getenv("VGA_TRACE") != nullptr;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    static auto prev = t0;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[vgh-trace] %-44s +%9.3f ms  (at %9.3f ms)\n", what, std::chrono::duration<double, std::milli>(t - prev).count(),
+            std::chrono::duration<double, std::milli>(t - t0).count());
+    prev = t;
+}
+
 std::vector<QuerySequence> read_seqs_from_file(const std::string &filename)
 {
     std::ifstream in(filename);
@@ -110,6 +122,19 @@ std::string gaf_from_chain(const Index &ix, const QuerySequence &q, const vga_ma
     out.push_back('\t'); put_u64(out, m->query_begin[last] + k); out += "\t+\t"; out += path;
     out += "\t0\t0\t0\t0\t0\t0\tta:Z:chain,n_anchors: "; put_u64(out, c1 - c0); out.push_back('\n');
     return out;
+}
+
+// the same record with the path column already written (vga_chain_paths_text: the GPU formats it)
+void gaf_from_chain_text(std::string &out, const Index &ix, const QuerySequence &q, const vga_map_result *m, uint64_t read, uint64_t chain,
+                         const char *path, uint64_t path_len)
+{
+    if (m->chain_placeholder[chain]) { out += gaf_placeholder(q); return; }
+    const uint64_t a0 = m->anchor_off[read];
+    const uint64_t c0 = m->chain_anchor_off[chain], c1 = m->chain_anchor_off[chain + 1];
+    const uint64_t first = a0 + m->chain_anchor_idx[c0], last = a0 + m->chain_anchor_idx[c1 - 1];
+    out += q.name; out.push_back('\t'); put_u64(out, q.seq.size()); out.push_back('\t'); put_u64(out, m->query_begin[first]);
+    out.push_back('\t'); put_u64(out, m->query_begin[last] + ix.kmer_length); out += "\t+\t"; out.append(path, path_len);
+    out += "\t0\t0\t0\t0\t0\t0\tta:Z:chain,n_anchors: "; put_u64(out, c1 - c0); out.push_back('\n');
 }
 
 std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a, uint64_t r)
@@ -243,8 +268,9 @@ std::string text_of_reads(uint64_t n, unsigned n_threads, F per_read)
 
 unsigned text_threads()
 {
+    // (the heavy part of the GAF text -- the chains' path column -- comes from the GPU; what is left is copying)
     if (const char *e = getenv("VGA_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
-    return std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    return std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
 }
 
 struct ChunkOut {
@@ -289,11 +315,17 @@ ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequenc
     // chains GAF (map.rs:123-145): every chain of every read, in order.  Text generation is host work that only reads the
     // chains: it runs beside the alignment call, which keeps the GPU busy
     const unsigned T = text_threads();
+    // the path column of every chain is written by the GPU (K6, before the alignment call takes it over); the records are
+    // put together around it on a host thread beside that call
+    vga_chain_text *ct = nullptr;
+    if (vga_chain_paths_text(ctx, m, &ct) != VGA_OK) { const std::string e = vga_last_error(ctx); vga_map_result_free(m); vga_batch_destroy(b); throw Error(e); }
+    mark("vga_chain_paths_text");
     std::string chain_err;
     std::thread chains_thread([&]() {
         try {
             out.chains = text_of_reads(n, opt.also_align ? std::max(1u, T / 2) : T, [&](uint64_t r, std::string &dst) {
-                for (uint64_t c = m->chain_off[r]; c < m->chain_off[r + 1]; c++) dst += gaf_from_chain(ix, inputs[b0 + r], m, r, c);
+                for (uint64_t c = m->chain_off[r]; c < m->chain_off[r + 1]; c++)
+                    gaf_from_chain_text(dst, ix, inputs[b0 + r], m, r, c, ct->text + ct->text_off[c], ct->text_off[c + 1] - ct->text_off[c]);
             });
         } catch (const std::exception &e) { chain_err = e.what(); }
     });
@@ -305,6 +337,7 @@ ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequenc
         if (vga_align_batch(b, m, (uint32_t)opt.align_best_n, &pp, &a) != VGA_OK) {
             const std::string e = vga_last_error(ctx);
             chains_thread.join();
+            vga_chain_text_free(ct);
             vga_map_result_free(m); vga_batch_destroy(b);
             throw Error(e);
         }
@@ -318,6 +351,7 @@ ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequenc
     }
     chains_thread.join();
     mark("chains GAF text (joined)");
+    vga_chain_text_free(ct);
     if (!chain_err.empty()) { vga_map_result_free(m); vga_batch_destroy(b); throw Error(chain_err); }
     vga_map_result_free(m);
     vga_batch_destroy(b);
@@ -377,10 +411,12 @@ MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequen
 MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt, const std::string &out_prefix)
 {
     check_aligner(opt);
+    trace_mark("map_reads_multi: start");
     // one context per device slot; with no list, every GPU vga_ctx_create accepts
     std::vector<vga_ctx *> ctxs;
     auto release = [&]() { for (vga_ctx *c : ctxs) vga_ctx_destroy(c); ctxs.clear(); };
     std::vector<int> devs = opt.devices;
+    if (devs.empty() && !opt.all_devices) devs.push_back(opt.device);
     if (devs.empty()) {
         for (int d = 0; d < 64; d++) {
             vga_ctx *c = nullptr;
@@ -396,6 +432,7 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
         }
     }
     const uint32_t n_slots = (uint32_t)ctxs.size();
+    trace_mark("contexts created");
     // contexts that share a GPU share its memory: each takes its part of the traceback pool
     if (!devs.empty() && !getenv("VGA_POOL_FRACTION")) {
         size_t most = 1;
@@ -409,6 +446,7 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
         for (vga_ctx *c : ctxs)
             if (vga_index_upload(c, &d) != VGA_OK) { const std::string e = vga_last_error(c); release(); throw Error(e); }
     }
+    trace_mark("index uploaded");
     // the library's worker threads (subgraph extraction, CIGAR strings) are per call: share the cores between the slots
     if (n_slots > 1 && !getenv("VGA_HOST_THREADS")) {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -471,8 +509,12 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
             }
         });
     for (std::thread &t : workers) t.join();
+    trace_mark("chunks mapped and aligned");
     if (writer.joinable()) writer.join();
-    release();
+    trace_mark("GAF files written");
+    if (opt.leave_contexts) ctxs.clear();
+    else release();
+    trace_mark("contexts destroyed");
     for (const std::string &e : errors)
         if (!e.empty()) throw Error(e);
     if (!writer_err.empty()) throw Error(writer_err);

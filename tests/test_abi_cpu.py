@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 # every struct of include/vga_hip.h and the ctypes class binding.py declares for it
 ABI_STRUCTS = {
     "vga_kmerpos": "KmerPos", "vga_index_desc": "IndexDesc", "vga_map_params": "MapParams", "vga_map_result": "MapResult",
-    "vga_poa_params": "PoaParams", "vga_poa_result": "PoaResult", "vga_align_result": "AlignResult", "vga_kernel_time": "KernelTime",
+    "vga_poa_params": "PoaParams", "vga_poa_result": "PoaResult", "vga_align_result": "AlignResult", "vga_kernel_time": "KernelTime", "vga_chain_text": "ChainText",
 }
 
 
