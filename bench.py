@@ -94,7 +94,7 @@ def main():
         GFA = os.path.join(tempfile.mkdtemp(prefix="vga_bench_"), args.workload + ".gfa")
         if args.workload == "config4":
             nn, ne, nb_ = pkg.readsim.config4_graph(os.path.join(ROOT, "tests", "golden", "data"), GFA)
-            wl_name = "config4: 19 HLA-zoo loci, sorted (readsim.toposort_gfa) and merged (%d nodes, %d bp)" % (nn, nb_)
+            wl_name = "config4: 19 of the 20 HLA-zoo loci (7-MICB-4277 left out: cyclic after sorting, the reference k-mer enumeration does not terminate on it), sorted (readsim.toposort_gfa) and merged (%d nodes, %d bp)" % (nn, nb_)
         else:
             nn, ne, nb_ = pkg.readsim.synth_pangenome(GFA)
             wl_name = "config5: synthetic pangenome (%d nodes, %d bp)" % (nn, nb_)
@@ -310,6 +310,7 @@ def main():
         "cpu_baseline_faithful": cpu_faithful,
         "cpu_baseline_all_cores": cpu_all,
         "reads_per_s": round(reads_all * args.steps / elapsed, 2),
+        "whole_job": {"reads": int(reads_all), "aligned": int(aligned_all), "ranks": world},  # per step, summed over the ranks
         "per_step": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in last.items() if k != "kernels"},
         # sum of every launch's own duration: launches of poa_band_dp overlap (three in flight), so this is NOT time per step
         "kernels_summed_launch_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in kern.items()},

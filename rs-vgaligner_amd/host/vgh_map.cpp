@@ -321,6 +321,10 @@ ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequenc
     if (vga_chain_paths_text(ctx, m, &ct) != VGA_OK) { const std::string e = vga_last_error(ctx); vga_map_result_free(m); vga_batch_destroy(b); throw Error(e); }
     mark("vga_chain_paths_text");
     std::string chain_err;
+    struct joiner {  // (an exception below must not leave the thread joinable: std::terminate)
+        std::thread &t;
+        ~joiner() { if (t.joinable()) t.join(); }
+    };
     std::thread chains_thread([&]() {
         try {
             out.chains = text_of_reads(n, opt.also_align ? std::max(1u, T / 2) : T, [&](uint64_t r, std::string &dst) {
@@ -329,6 +333,7 @@ ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequenc
             });
         } catch (const std::exception &e) { chain_err = e.what(); }
     });
+    joiner chains_joiner{chains_thread};
     if (opt.also_align) {
         vga_poa_params pp;
         vga_poa_default_params(&pp);
@@ -433,6 +438,14 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
     }
     const uint32_t n_slots = (uint32_t)ctxs.size();
     trace_mark("contexts created");
+    // the two settings below travel to the library through the environment: what was there before comes back at the end
+    struct env_keeper {
+        const char *name;
+        bool had;
+        std::string old;
+        explicit env_keeper(const char *n) : name(n), had(getenv(n) != nullptr), old(had ? getenv(n) : "") {}
+        ~env_keeper() { if (had) setenv(name, old.c_str(), 1); else unsetenv(name); }
+    } keep_fraction("VGA_POOL_FRACTION"), keep_threads("VGA_HOST_THREADS");
     // contexts that share a GPU share its memory: each takes its part of the traceback pool
     if (!devs.empty() && !getenv("VGA_POOL_FRACTION")) {
         size_t most = 1;
@@ -466,7 +479,7 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
     std::mutex mu;
     std::condition_variable cv;
     std::vector<uint8_t> done(plan.size(), 0);
-    bool abort_writer = false;
+    bool abort_writer = false, abort_workers = false;
     std::string writer_err;
     std::thread writer;
     if (stream)
@@ -490,7 +503,11 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
                     std::string().swap(parts[i].chains);
                     std::string().swap(parts[i].aligns);
                 }
-            } catch (const std::exception &e) { writer_err = e.what(); }
+            } catch (const std::exception &e) {
+                writer_err = e.what();
+                std::lock_guard<std::mutex> lk(mu);
+                abort_workers = true;  // (nothing that is still to be mapped could be written)
+            }
         });
     std::vector<std::thread> workers;
     for (uint32_t slot = 0; slot < n_slots; slot++)
@@ -498,6 +515,7 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
             try {
                 for (size_t i = 0; i < plan.size(); i++)
                     if (plan[i].slot == slot) {
+                        { std::lock_guard<std::mutex> lk(mu); if (abort_workers) break; }
                         parts[i] = map_chunk(ctxs[slot], ix, inputs, plan[i].begin, plan[i].end, opt);
                         { std::lock_guard<std::mutex> lk(mu); done[i] = 1; }
                         cv.notify_all();

@@ -123,3 +123,44 @@ def test_cli_streams_chunks_over_several_contexts_with_identical_output(tmp_path
     al = open(os.path.join(d, "two-alignments.gaf")).read().splitlines()
     assert [ln.split("\t")[0] for ln in al] == [r.name for r in reads]
     assert sum(1 for ln in al if ln.split("\t")[5] != "*") >= 1990
+
+
+@pytest.mark.gpu
+def test_cli_two_contexts_on_the_merged_hla_graph_with_full_length_reads(tmp_path, config4_gfa):
+    """BASELINE config #4 at reduced count through the product driver: 2 000 full-length (10 kbp or the whole path) reads of the
+    19 merged HLA-zoo loci, `--devices 0,0 --chunk-reads 350` (two contexts sharing the GPU, six batches) against one context
+    and one batch -- byte-identical GAF files, every read aligned, records in read order (src/map.rs:56-111,162-167)."""
+    p = pkg()
+    d = str(tmp_path)
+    reads = p.readsim.config3_reads(config4_gfa, 2000)
+    fa = os.path.join(d, "r.fa")
+    p.readsim.write_fasta(reads, fa)
+    run(["index", "-i", config4_gfa, "-k", "11", "-o", os.path.join(d, "hla")], d)
+    base = ["map", "-i", os.path.join(d, "hla"), "-f", fa, "-p", "abpoa", "-D", "-G", config4_gfa]
+    one = run(base + ["-o", os.path.join(d, "one"), "--device", "0", "--chunk-reads", "0"], d)
+    two = run(base + ["-o", os.path.join(d, "two"), "--devices", "0,0", "--chunk-reads", "350"], d)
+    assert "1 GPU context(s), 1 batch(es)" in one.stderr and "2 GPU context(s), 6 batch(es)" in two.stderr
+    for suffix in ("-chains.gaf", "-alignments.gaf"):
+        a, b = open(os.path.join(d, "one" + suffix)).read(), open(os.path.join(d, "two" + suffix)).read()
+        assert a == b and a.count("\n") >= 2000
+    al = open(os.path.join(d, "two-alignments.gaf")).read().splitlines()
+    assert [ln.split("\t")[0] for ln in al] == [r.name for r in reads]
+    assert sum(1 for ln in al if ln.split("\t")[5] != "*") >= 1990
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_under_torch_distributed_on_one_gpu():
+    """The N > 1 path of bench.py as the driver launches it (python -m torch.distributed.run --nproc-per-node 2 ... bench.py
+    --gpus 2), rehearsed on the one GPU of the test box (VGA_BENCH_REHEARSAL=1: ranks share the GPU, gloo instead of RCCL for
+    the barrier and the max-over-ranks reduction).  One JSON line from rank 0, n_gpus 2, both ranks' reads in the total."""
+    env = dict(os.environ, VGA_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", VGA_POOL_FRACTION="0.4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--reads", "300", "--cpu-sample", "0"]
+    pr = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 1
+    assert j["whole_job"]["reads"] == 600 and 590 <= j["whole_job"]["aligned"] <= 600
+    assert abs(j["value"] - j["whole_job"]["aligned"] / (j["ms_per_step"] * 1e-3)) <= 0.01 * j["value"]
