@@ -432,7 +432,7 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
     } else {
         for (int d : devs) {
             vga_ctx *c = nullptr;
-            if (vga_ctx_create(d, &c) != VGA_OK) { release(); throw Error("cannot create a context on device " + std::to_string(d) + " (this build has no CPU path)"); }
+            if (vga_ctx_create(d, &c) != VGA_OK) { release(); throw Error("no MI355X device available: cannot create a context on device " + std::to_string(d) + " (this build has no CPU path)"); }
             ctxs.push_back(c);
         }
     }
