@@ -142,6 +142,23 @@ def main():
     elapsed, aligned_all, reads_all = pkg.sharding.reduce_timing(elapsed, last["aligned"], last["n_reads"], world,
                                                                  device="cuda" if world > 1 and not rehearsal else None)
 
+    # the same batch under the OTHER remain rule (vga_poa_params.remain_rule: the open choice of the POA restatement with first-order
+    # effects on cost), one untimed-region step on rank 0: reported beside the line's value, never part of it
+    other_rule = None
+    if rank == 0 and world == 1 and not map_only and not os.environ.get("VGA_BENCH_NO_OTHER_RULE"):
+        try:
+            pp2 = pkg.default_poa_params()
+            pp2.remain_rule = 1 - args.remain_rule
+            batch.map_align_raw(poa_params=pp2)  # (warm-up: the footprint scale adapts)
+            t_o = time.perf_counter()
+            lo = batch.map_align_raw(poa_params=pp2)
+            dt_o = time.perf_counter() - t_o
+            other_rule = {"poa_remain_rule": ["longest-path", "first-out-edge"][1 - args.remain_rule], "value": round(lo["aligned"] / dt_o, 2),
+                          "unit": "aligned reads/s", "poa_cells": lo["poa_cells"], "steps": 1,
+                          "note": "same reads, one step after the timed region; which rule the reference's abPOA computes is unverified (DESIGN.md section 2)"}
+        except Exception as e:  # noqa: BLE001
+            other_rule = {"error": str(e)[:200]}
+
     # measured device-to-device copy rate next to the nominal HBM peak (read + write bytes of 1 GiB copies).  After the timed
     # region: torch allocations made before it leave less HBM for the library's traceback pool (-10 % on the step)
     copy_gbs = None
@@ -306,6 +323,7 @@ def main():
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "sharding": "reads, replicated index, no collective",
                    "poa_remain_rule": ["longest-path", "first-out-edge"][args.remain_rule]},
         "roofline": roofline,
+        "other_remain_rule": other_rule,
         "cpu_baseline": cpu,
         "cpu_baseline_faithful": cpu_faithful,
         "cpu_baseline_all_cores": cpu_all,
