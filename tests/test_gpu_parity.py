@@ -459,6 +459,19 @@ def test_poa_query_longer_than_a_pool_chunk_of_scratch(oracle, ctx):
     _check_poa(oracle, ctx, [(["ACGT", "TTGA"], [(0, 1)], q), bubble])
 
 
+@_long_ok
+def test_poa_230_kbp_query_with_the_long_problem_launch_shape(oracle, ctx, monkeypatch):
+    """very long problems are launched with 1 024 threads and an 8 192-column LDS window; beyond ~228 kbp the query's
+    column codes leave no room for that window.  The launch then halves the window (and only steps the workgroup through
+    instantiated sizes) instead of failing the call.  VGA_POA_WINDOW / VGA_POA_NT pin the shape poa_feed::klass selects."""
+    monkeypatch.setenv("VGA_POA_WINDOW", "8192")
+    monkeypatch.setenv("VGA_POA_NT", "1024")
+    rng = random.Random(230)
+    q = "".join(rng.choice("ACGT") for _ in range(230000))
+    g = [q[100000 + i:100000 + i + 7] for i in range(0, 28, 7)]
+    _check_poa(oracle, ctx, [(g, [(0, 1), (1, 2), (2, 3), (0, 2)], q), (["ACGT", "TTGA"], [(0, 1)], q[:229000])])
+
+
 def _fallback_problems(rng):
     return [_rand_problem(rng, rng.randint(1, 40), 6) for _ in range(30)] + [_rand_problem(rng, 60, 60) for _ in range(2)]
 
