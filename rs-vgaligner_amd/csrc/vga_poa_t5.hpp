@@ -516,9 +516,11 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
         // nothing else exists; the other copy keeps every path.  (Cells that no predecessor cell reaches hold values near
         // 4 POA_NEG; only that they stay far below every real score matters, not their exact value.)
         const bool hot = (simple || staged) && !wide && q_plain;
+        const int rlim = end < pend ? end : pend;
         auto run_steps = [&](auto hot_c) __attribute__((always_inline)) {
         constexpr bool HOT = decltype(hot_c)::value;
         int carry1 = POA_IDENT, carry2 = POA_IDENT, left1 = POA_IDENT, left2 = POA_IDENT;
+        int next_left = 0;
         int buf = 0;
         for (int c0 = 0; c0 < W; c0 += STEP, buf ^= 1) {
             uint32_t f = HOT ? (rowf & (F_KEEP | F_SINK)) : rowf;
@@ -527,8 +529,16 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
             const int c = c0 + 4 * tid;
             const int j0 = bal + c;
             const bool lane_act = j0 <= end;
-            const int nw_step = (W - c0 + 255) / 256 < NW ? (W - c0 + 255) / 256 : NW;
-            const bool wave_act = wv < nw_step;
+            // the mask-free path and its edge patches (lp / rp / lq).  Kept as integers: a boolean made of several compares
+            // lives in a 64-bit lane mask, with a select and an AND in front of every branch on it
+            const int jw0 = bal + c0 + 256 * wv, jw1 = jw0 + 255;
+            const bool wave_act = jw0 <= end;  // (this wave has columns in this step: 256 wv < W - c0)
+            int d_lp = jw0 - beg, d_rp = rlim - jw1, d_lq = (jw0 > beg ? jw0 : beg) - pbeg - 1;  // each negative when its patch applies
+            asm volatile("" : "+s"(d_lp), "+s"(d_rp), "+s"(d_lq));
+            const uint32_t e_lp = (uint32_t)d_lp >> 31;  // jw0 < beg
+            const uint32_t e_rp = (uint32_t)d_rp >> 31;  // jw1 > min(end, pend)
+            const uint32_t e_lq = (uint32_t)d_lq >> 31;  // max(jw0, beg) <= pbeg
+            const bool lp = e_lp != 0, rp = e_rp != 0, lq = e_lq != 0;
             // carried from phase 1 to phase 2, per cell: Ht' (tagged), 4 Ht, E1' (tag 1), E2' (tag 0)
             int htt[4], ht4[4], e1t[4], e2t[4], pmeta[4];
             int agg1 = POA_IDENT, agg2 = POA_IDENT, alast1 = POA_IDENT, alast2 = POA_IDENT;
@@ -536,11 +546,6 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
             for (int k = 0; k < 4; k++) { htt[k] = T4_NEG + 2; ht4[k] = T4_NEG; e1t[k] = T4_NEG + 1; e2t[k] = T4_NEG; pmeta[k] = 0; }
             uint32_t qn = 0u;
             if (wave_act) qn = (uint32_t)Qn[j0 >> 2];
-            // the mask-free path and its edge patches (lp / rp / lq): see k_poa_dp_pk
-            const int jw0 = bal + c0 + 256 * wv, jw1 = jw0 + 255;
-            const bool lp = jw0 < beg;
-            const bool rp = jw1 > end || jw1 > pend;
-            const bool lq = (lp ? beg : jw0) <= pbeg;
             const bool fastw = HOT ? wave_act
                                    : (f & (F_SINGLE | F_PLAIN)) == (F_SINGLE | F_PLAIN) && wave_act && (!lq || (f & F_NEAR)) && (!rp || ((f & F_NEAR) && end <= pend + 1));
             const int base1 = 4 * e1 * j0, base2 = 4 * e2 * j0;  // the scan runs on lane-relative values in the fast path
@@ -549,7 +554,18 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
                 int4 hv;
                 uint2 gg;
                 int hprev;
-                if (__builtin_expect((f & F_NEAR) != 0, 1)) {
+                if constexpr (HOT) {
+                    // the column left of a lane's four is the last word of the lane below (DPP); lane 0 of a wave takes it
+                    // from LDS with a broadcast read: column jw0 - 1, or -- first wave of a later step, whose left neighbour
+                    // the last lane overwrote in the step before -- the word the first wave parked then (next_left)
+                    hv = *(const int4 *)(Hs + (j0 & win_mask));
+                    gg = *(const uint2 *)(Gs + (j0 & win_mask));
+                    int left0;
+                    if (wv == 0 && c0 > 0) left0 = next_left;
+                    else left0 = Hs[(jw0 > 0 ? jw0 - 1 : 0) & (int)win_mask];
+                    if (wv == 0 && c0 + STEP < W) next_left = Hs[(jw0 + STEP - 1) & (int)win_mask];
+                    hprev = t4_shr1_mov(hv.w, left0);
+                } else if (__builtin_expect((f & F_NEAR) != 0, 1)) {
                     hv = *(const int4 *)(Hs + (j0 & win_mask));
                     gg = *(const uint2 *)(Gs + (j0 & win_mask));
                     if (tid == NT - 1) edgeW[buf] = hv.w;
@@ -624,7 +640,7 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
                     alast1 = r13 + base1;
                     alast2 = r23 + base2;
                 };
-                if (__builtin_expect(lp || rp || lq, 0)) phase1(std::true_type{});
+                if (__builtin_expect((e_lp | e_rp | e_lq) != 0, 0)) phase1(std::true_type{});
                 else phase1(std::false_type{});
         if constexpr (HOT) POA_MARK("hot_p1_lean"); else POA_MARK("p1_lean");
             } else if (wave_act && (f & F_SINGLE)) {
@@ -899,7 +915,7 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
                             }
                         }
                     };
-                    if (__builtin_expect(lp || rp, 0)) phase2(std::true_type{});
+                    if (__builtin_expect((e_lp | e_rp) != 0, 0)) phase2(std::true_type{});
                     else phase2(std::false_type{});
         if constexpr (HOT) POA_MARK("hot_p2_slow"); else POA_MARK("p2_slow");
                 } else if (lane_act) {
