@@ -143,7 +143,10 @@ void vga_map_result_free(vga_map_result *r);
  * (src/chain.rs:90-127): for each anchor of a chain, in order, "(>N:off,>N:off)," = node id and offset inside the node of
  * target_begin and of the inclusive target_end.  `text` holds the fields of all chains back to back, without terminators;
  * chain c's field is text[text_off[c] .. text_off[c + 1]) (empty for a placeholder chain).  Forward-strand anchors only
- * (vga_map_params.only_forward = 1, the reference's only live setting). */
+ * (vga_map_params.only_forward = 1, the reference's only live setting).
+ * Threads: the one call on a context that may run beside another -- one thread may be in vga_chain_paths_text while
+ * another is in vga_align_batch on the same context (it works on a stream of its own and shares only the index and, on
+ * failure, the error string). */
 typedef struct {
     uint64_t n_chains;
     uint64_t *text_off; /* n_chains + 1 */

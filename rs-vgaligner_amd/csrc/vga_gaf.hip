@@ -129,6 +129,8 @@ struct gaf_ws {
     vga_dbuf<char> d_text;
     vga_hbuf<gaf_chain> h_chains;
     vga_hbuf<uint64_t> h_len;
+    hipStream_t st = nullptr;  // its own stream: the call may run beside vga_align_batch on the same context
+    ~gaf_ws() { if (st) (void)hipStreamDestroy(st); }
 };
 
 }  // namespace
@@ -137,7 +139,7 @@ extern "C" void vga_chain_text_free(vga_chain_text *t)
 {
     if (!t) return;
     free(t->text_off);
-    if (t->text) (void)hipHostFree(t->text);
+    free(t->text);
     free(t);
 }
 
@@ -147,12 +149,13 @@ static int vga_chain_paths_text_impl(vga_ctx *ctx, const vga_map_result *m, vga_
     *out = nullptr;
     if (!ctx->index.loaded) return vga_set_error(ctx, VGA_ERR_NO_INDEX, "vga_chain_paths_text: no index uploaded");
     (void)hipSetDevice(ctx->device);
-    hipStream_t st = ctx->stream;
+    hipStream_t st = nullptr;
     auto t_begin = std::chrono::steady_clock::now();
 #define GAF_CHECK(call)                                                                                                                  \
     do {                                                                                                                                \
         hipError_t e_ = (call);                                                                                                         \
         if (e_ != hipSuccess) {                                                                                                         \
+            if (st) (void)hipStreamSynchronize(st);                                                                                     \
             vga_chain_text_free(res);                                                                                                   \
             return vga_set_error(ctx, e_ == hipErrorOutOfMemory ? VGA_ERR_NOMEM : VGA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
                                  __FILE__, __LINE__);                                                                                   \
@@ -172,6 +175,8 @@ static int vga_chain_paths_text_impl(vga_ctx *ctx, const vga_map_result *m, vga_
         ctx->gaf_ws_free = [](void *q) { delete (gaf_ws *)q; };
     }
     gaf_ws &W = *(gaf_ws *)ctx->gaf_ws;
+    if (!W.st) GAF_CHECK(hipStreamCreateWithFlags(&W.st, hipStreamNonBlocking));
+    st = W.st;
     GAF_CHECK(W.h_chains.reserve(nc)); GAF_CHECK(W.d_chains.reserve(nc)); GAF_CHECK(W.h_len.reserve(nc)); GAF_CHECK(W.d_len.reserve(nc));
     GAF_CHECK(W.d_member.reserve(n_members)); GAF_CHECK(W.d_tb.reserve(m->n_anchors + 1)); GAF_CHECK(W.d_te.reserve(m->n_anchors + 1));
     {
@@ -195,7 +200,9 @@ static int vga_chain_paths_text_impl(vga_ctx *ctx, const vga_map_result *m, vga_
     for (uint64_t c = 0; c < nc; c++) { res->text_off[c] = tot; W.h_chains.p[c].text0 = tot; tot += W.h_len.p[c]; }
     res->text_off[nc] = tot;
     GAF_CHECK(W.d_text.reserve(tot + 64));
-    GAF_CHECK(hipHostMalloc((void **)&res->text, tot + 64, hipHostMallocDefault));
+    // (pageable: the runtime stages the copy at ~20 GB/s; a pinned buffer of this size costs more to allocate than that)
+    res->text = (char *)malloc(tot + 64);
+    if (!res->text) { vga_chain_text_free(res); return vga_set_error(ctx, VGA_ERR_NOMEM, "out of host memory (chain text, %llu bytes)", (unsigned long long)tot); }
     GAF_CHECK(hipMemcpyAsync(W.d_chains.p, W.h_chains.p, nc * sizeof(gaf_chain), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_gaf_chain_write, dim3(grid), dim3(64), 0, st, (uint32_t)nc, W.d_chains.p, W.d_member.p, W.d_tb.p, W.d_te.p, ix.d_node_start,
                        (uint32_t)ix.n_nodes, W.d_text.p);

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <memory>
 
 #define VGA_WAVE 64
 #define VGA_PROBE_NT 256
@@ -407,9 +408,8 @@ struct map_ws {
     vga_dbuf<uint64_t> chain_woff;
     vga_hbuf<uint64_t> h_chain_woff;
     // pinned staging for the result copies (pageable D2H runs at a fraction of the PCIe rate)
-    vga_hbuf<uint32_t> h_id, h_qb, h_tb, h_te, h_chain_buf, h_chain_cnt, h_chain_words, h_cnt;
-    vga_hbuf<double> h_f, h_curr_max;
-    vga_hbuf<int32_t> h_pred;
+    vga_hbuf<uint32_t> h_chain_cnt, h_chain_words, h_cnt;
+    vga_hbuf<double> h_curr_max;
     // the sorted anchor coordinates go back to the host on a second stream while the chaining kernel runs
     hipStream_t st_copy = nullptr;
     hipEvent_t ev_sorted = nullptr;
@@ -497,6 +497,8 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
     do {                                                                                             \
         hipError_t e_ = (call);                                                                      \
         if (e_ != hipSuccess) {                                                                      \
+            (void)hipStreamSynchronize(st); /* (copies into the result's arrays may be in flight) */ \
+            if (ws.st_copy) (void)hipStreamSynchronize(ws.st_copy);                                  \
             vga_map_result_free(res);                                                                \
             return vga_set_error(ctx, VGA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
                                  __LINE__);                                                          \
@@ -577,19 +579,14 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
     hipLaunchKernelGGL(k_anchor_gather_seg, dim3((unsigned)R), dim3(256), 0, st, ws.anchor_off.p, perm, ws.a_qb.p, ws.a_tb.p,
                        ws.a_te.p, ws.s_qb.p, ws.s_tb.p, ws.s_te.p);
     vga_timer_end(ctx, t3);
-    // the sorted coordinates are final: copy them back next to the chaining kernel
+    // the sorted coordinates are final: they go back beside the chaining kernel (below, once it is launched)
     if (!ws.st_copy) {
         MAP_CHECK(hipStreamCreateWithFlags(&ws.st_copy, hipStreamNonBlocking));
         MAP_CHECK(hipEventCreateWithFlags(&ws.ev_sorted, hipEventDisableTiming));
     }
-    MAP_CHECK(ws.h_qb.reserve(An)); MAP_CHECK(ws.h_tb.reserve(An)); MAP_CHECK(ws.h_te.reserve(An));
     MAP_CHECK(hipEventRecord(ws.ev_sorted, st));
     MAP_CHECK(hipStreamWaitEvent(ws.st_copy, ws.ev_sorted, 0));
-    if (An) {
-        MAP_CHECK(hipMemcpyAsync(ws.h_qb.p, ws.s_qb.p, An * 4, hipMemcpyDeviceToHost, ws.st_copy));
-        MAP_CHECK(hipMemcpyAsync(ws.h_tb.p, ws.s_tb.p, An * 4, hipMemcpyDeviceToHost, ws.st_copy));
-        MAP_CHECK(hipMemcpyAsync(ws.h_te.p, ws.s_te.p, An * 4, hipMemcpyDeviceToHost, ws.st_copy));
-    }
+    tr.mark("probe + sort launches");
 
     // ---- K3: chain DP + backtracking
     int t4 = vga_timer_begin(ctx, "chain_dp", 16 * total + 12 * total);
@@ -607,33 +604,12 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
     vga_timer_end(ctx, t4);
     vga_timer_end(ctx, t_total);
 
-    tr.mark("launches");
-    // ---- results to host: async copies into pinned staging, then a threaded fan-out into the result arrays
+    tr.mark("chain launch");
+    // ---- results to host.  The per-anchor arrays go straight into the result's own (pageable) arrays: the runtime stages
+    // such a copy through its own pinned buffers at ~20 GB/s, where pinned staging of our own costs a hipHostMalloc of the
+    // same size first (60-90 ms per 400 MB, tests/microbench/pinned_time.hip) and a fan-out copy afterwards.  The small
+    // per-read arrays keep their pinned staging.
     const bool emit_dp = params->emit_dp != 0;
-    if (emit_dp) { MAP_CHECK(ws.h_id.reserve(An)); MAP_CHECK(ws.h_f.reserve(An)); MAP_CHECK(ws.h_pred.reserve(An)); }
-    MAP_CHECK(ws.h_curr_max.reserve(R)); MAP_CHECK(ws.h_chain_cnt.reserve(R)); MAP_CHECK(ws.h_chain_words.reserve(R));
-    MAP_CHECK(ws.h_chain_woff.reserve(R + 1)); MAP_CHECK(ws.chain_woff.reserve(R + 1));
-    // the per-read counts first: they say how much of the chain buffer is in use
-    MAP_CHECK(hipMemcpyAsync(ws.h_curr_max.p, ws.curr_max.p, R * 8, hipMemcpyDeviceToHost, st));
-    MAP_CHECK(hipMemcpyAsync(ws.h_chain_cnt.p, ws.chain_cnt.p, R * 4, hipMemcpyDeviceToHost, st));
-    MAP_CHECK(hipMemcpyAsync(ws.h_chain_words.p, ws.chain_words.p, R * 4, hipMemcpyDeviceToHost, st));
-    if (An && emit_dp) {
-        MAP_CHECK(hipMemcpyAsync(ws.h_id.p, perm, An * 4, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(ws.h_f.p, ws.f.p, An * 8, hipMemcpyDeviceToHost, st));
-        MAP_CHECK(hipMemcpyAsync(ws.h_pred.p, ws.pred_id.p, An * 4, hipMemcpyDeviceToHost, st));
-    }
-    MAP_CHECK(hipStreamSynchronize(st));
-    uint64_t chain_total_words = 0;
-    for (uint64_t r = 0; r < R; r++) { ws.h_chain_woff.p[r] = chain_total_words; chain_total_words += ws.h_chain_words.p[r]; }
-    ws.h_chain_woff.p[R] = chain_total_words;
-    MAP_CHECK(ws.h_chain_buf.reserve(chain_total_words + 2));
-    if (chain_total_words) {
-        MAP_CHECK(ws.chain_comp.reserve(chain_total_words + 2));
-        MAP_CHECK(hipMemcpyAsync(ws.chain_woff.p, ws.h_chain_woff.p, (R + 1) * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_chain_compact, dim3((unsigned)R), dim3(256), 0, st, ws.anchor_off.p, ws.chain_words.p, ws.chain_woff.p,
-                           ws.chain_buf.p, ws.chain_comp.p);
-        MAP_CHECK(hipMemcpyAsync(ws.h_chain_buf.p, ws.chain_comp.p, chain_total_words * 4, hipMemcpyDeviceToHost, st));
-    }
     if (emit_dp) {
         res->anchor_id = xmalloc<uint32_t>(An);
         res->max_chain_score = xmalloc<double>(An);
@@ -647,30 +623,41 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
         (void)hipStreamSynchronize(ws.st_copy);
         return nomem();
     }
+    if (An) {  // (beside the chaining kernel: these wait for the sort only)
+        MAP_CHECK(hipMemcpyAsync(res->query_begin, ws.s_qb.p, An * 4, hipMemcpyDeviceToHost, ws.st_copy));
+        MAP_CHECK(hipMemcpyAsync(res->target_begin, ws.s_tb.p, An * 4, hipMemcpyDeviceToHost, ws.st_copy));
+        MAP_CHECK(hipMemcpyAsync(res->target_end, ws.s_te.p, An * 4, hipMemcpyDeviceToHost, ws.st_copy));
+    }
+    MAP_CHECK(ws.h_curr_max.reserve(R)); MAP_CHECK(ws.h_chain_cnt.reserve(R)); MAP_CHECK(ws.h_chain_words.reserve(R));
+    MAP_CHECK(ws.h_chain_woff.reserve(R + 1)); MAP_CHECK(ws.chain_woff.reserve(R + 1));
+    // the per-read counts first: they say how much of the chain buffer is in use
+    MAP_CHECK(hipMemcpyAsync(ws.h_curr_max.p, ws.curr_max.p, R * 8, hipMemcpyDeviceToHost, st));
+    MAP_CHECK(hipMemcpyAsync(ws.h_chain_cnt.p, ws.chain_cnt.p, R * 4, hipMemcpyDeviceToHost, st));
+    MAP_CHECK(hipMemcpyAsync(ws.h_chain_words.p, ws.chain_words.p, R * 4, hipMemcpyDeviceToHost, st));
+    MAP_CHECK(hipStreamSynchronize(st));
+    uint64_t chain_total_words = 0;
+    for (uint64_t r = 0; r < R; r++) { ws.h_chain_woff.p[r] = chain_total_words; chain_total_words += ws.h_chain_words.p[r]; }
+    ws.h_chain_woff.p[R] = chain_total_words;
+    std::unique_ptr<uint32_t, void (*)(void *)> chain_words_host(xmalloc<uint32_t>(chain_total_words + 2), free);
+    if (!chain_words_host) { (void)hipStreamSynchronize(ws.st_copy); return nomem(); }
+    if (chain_total_words) {
+        MAP_CHECK(ws.chain_comp.reserve(chain_total_words + 2));
+        MAP_CHECK(hipMemcpyAsync(ws.chain_woff.p, ws.h_chain_woff.p, (R + 1) * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_chain_compact, dim3((unsigned)R), dim3(256), 0, st, ws.anchor_off.p, ws.chain_words.p, ws.chain_woff.p,
+                           ws.chain_buf.p, ws.chain_comp.p);
+        MAP_CHECK(hipMemcpyAsync(chain_words_host.get(), ws.chain_comp.p, chain_total_words * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (An && emit_dp) {
+        MAP_CHECK(hipMemcpyAsync(res->anchor_id, perm, An * 4, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(res->max_chain_score, ws.f.p, An * 8, hipMemcpyDeviceToHost, st));
+        MAP_CHECK(hipMemcpyAsync(res->best_pred_id, ws.pred_id.p, An * 4, hipMemcpyDeviceToHost, st));
+    }
     MAP_CHECK(hipStreamSynchronize(st));
     MAP_CHECK(hipStreamSynchronize(ws.st_copy));
     tr.mark("kernels + D2H");
     vga_timers_collect(ctx);
-    {
-        const uint64_t NCH = 64;  // chunks per array
-        vga_parallel_for(6 * NCH, [&](uint64_t job) {
-            const uint64_t arr = job / NCH, ch = job % NCH;
-            const uint64_t lo = An * ch / NCH, hi = An * (ch + 1) / NCH;
-            if (hi <= lo) return;
-            if (!emit_dp && (arr == 0 || arr >= 4)) return;
-            switch (arr) {
-            case 0: memcpy(res->anchor_id + lo, ws.h_id.p + lo, (hi - lo) * 4); break;
-            case 1: memcpy(res->query_begin + lo, ws.h_qb.p + lo, (hi - lo) * 4); break;
-            case 2: memcpy(res->target_begin + lo, ws.h_tb.p + lo, (hi - lo) * 4); break;
-            case 3: memcpy(res->target_end + lo, ws.h_te.p + lo, (hi - lo) * 4); break;
-            case 4: memcpy(res->max_chain_score + lo, ws.h_f.p + lo, (hi - lo) * 8); break;
-            default: memcpy(res->best_pred_id + lo, ws.h_pred.p + lo, (hi - lo) * 4); break;
-            }
-        }, (unsigned)std::max<uint64_t>(1, An / 500000));  // (a thread per ~6 MB: small batches are not worth the thread start-up)
-        memcpy(res->curr_max, ws.h_curr_max.p, R * 8);
-    }
-    const uint32_t *h_chain_cnt = ws.h_chain_cnt.p, *h_chain_words = ws.h_chain_words.p, *h_chain_buf = ws.h_chain_buf.p;
-    tr.mark("fan-out to result arrays");
+    memcpy(res->curr_max, ws.h_curr_max.p, R * 8);
+    const uint32_t *h_chain_cnt = ws.h_chain_cnt.p, *h_chain_words = ws.h_chain_words.p, *h_chain_buf = chain_words_host.get();
 
     // ---- chains: discovery order per read, members reversed to ascending (src/chain.rs:546);
     // a read without chains gets one placeholder (src/chain.rs:644-649)

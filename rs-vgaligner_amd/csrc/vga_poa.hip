@@ -27,6 +27,7 @@
 #include "vga_poa_internal.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <type_traits>
 #include <chrono>
@@ -219,6 +220,7 @@ struct poa_ws {
     // chunk pool (device side)
     vga_dbuf<unsigned long long> d_head;  // the free-list heads (POA_LISTS of them, a cache line apart), then the statistics
     vga_dbuf<uint32_t> d_next_chunk, d_slot_flag;
+    vga_hbuf<unsigned long long> h_empties; // where the keeper reads poa_chunk_pool::stats[0] to
     vga_hbuf<uint64_t> h_seg_base;        // staging of ...
     vga_dbuf<uint64_t> d_seg_base;        // ... the segment table the kernels read (an entry is copied before its chunks are listed)
     hipStream_t add_stream = nullptr;
@@ -554,6 +556,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 POA_CHECK(W.d_next_chunk.reserve(max_chunks));
                 POA_CHECK(W.d_slot_flag.reserve(16ull * (uint64_t)ctx->n_cu + 64));
                 POA_CHECK(W.h_seg_base.reserve(POA_MAX_SEGS));
+                POA_CHECK(W.h_empties.reserve(1));
                 POA_CHECK(W.d_seg_base.reserve(POA_MAX_SEGS));
                 if (!W.add_stream) {
                     POA_CHECK(hipStreamCreateWithFlags(&W.add_stream, hipStreamNonBlocking));
@@ -567,8 +570,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             }
         }
     }
-    // new segments' chunks join the free list (called before every launch; a tiny kernel on a stream of its own)
+    // new segments' chunks join the free list (a tiny kernel on a stream of its own), and requests that found every list empty
+    // make the pool grow.  Called before every launch and, every millisecond, by the keeper thread below
+    std::mutex list_mu;
     auto list_new_segments = [&]() -> hipError_t {
+        std::lock_guard<std::mutex> list_lk(list_mu);
         std::vector<poa_ws::seg_t> fresh;
         {
             std::lock_guard<std::mutex> lk(W.mu);
@@ -581,22 +587,45 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             hipLaunchKernelGGL(k_poa_chunks_add, dim3(1), dim3(64), 0, W.add_stream, CP, first, cnt);
             W.segs_listed++;
             W.chunks_listed += cnt;
+            if (tr.on && W.segs_listed > 1) fprintf(stderr, "[vga-trace] poa: segment %zu listed (%u chunks)\n", W.segs_listed, cnt);
         }
         hipError_t e = fresh.empty() ? hipSuccess : hipStreamSynchronize(W.add_stream);
         // requests that found the list empty: the pool is short of what the resident workgroups need -- more segments
-        if (e == hipSuccess && ++W.polls % 64 == 0) {
-            unsigned long long empties = 0;
-            e = hipMemcpyAsync(&empties, W.d_head.p + POA_LISTS * POA_LIST_STRIDE, sizeof empties, hipMemcpyDeviceToHost, W.add_stream);
+        if (e == hipSuccess && ++W.polls % 4 == 0) {
+            unsigned long long *empties = W.h_empties.p;
+            e = hipMemcpyAsync(empties, W.d_head.p + POA_LISTS * POA_LIST_STRIDE, sizeof *empties, hipMemcpyDeviceToHost, W.add_stream);
             if (e == hipSuccess) e = hipStreamSynchronize(W.add_stream);
-            if (e == hipSuccess && empties > W.empties_seen) {
-                W.empties_seen = empties;
+            // (one step at a time: what is counted while a step is still being allocated and listed is the shortage that
+            // step answers -- without this the target runs away, +50 % every few milliseconds)
+            bool settled;
+            { std::lock_guard<std::mutex> lk(W.mu); settled = !W.growing && W.segs_listed == W.segs.size(); }
+            if (e == hipSuccess && !settled) W.empties_seen = std::max<uint64_t>(W.empties_seen, *empties);
+            if (e == hipSuccess && settled && *empties > W.empties_seen) {
+                W.empties_seen = *empties;
                 uint64_t ps; { std::lock_guard<std::mutex> lk(W.mu); ps = std::max(W.pool_size, W.grow_target); }
                 const uint64_t more = std::min<uint64_t>(ps + ps / 2 + (4ull << 30), avail_pool);
                 if (more > ps) W.request(more);
+                if (tr.on) fprintf(stderr, "[vga-trace] poa: %llu requests have found every free list empty so far: pool target %.1f -> %.1f GB\n", *empties, (double)ps / 1e9, (double)more / 1e9);
             }
         }
         return e;
     };
+    // the keeper: the thread that runs this call may be held up for as long as a launch takes (a staging buffer that grows, the
+    // look-ahead preparation waiting for its kernel), and workgroups that wait for chunks meanwhile keep the launch from ending --
+    // so the pool is looked after by a thread that does nothing else
+    struct keeper_t {
+        std::atomic<bool> stop{false};
+        std::thread t;
+        ~keeper_t() { stop = true; if (t.joinable()) t.join(); }
+    } keeper;
+    if (n_arenas && !getenv("VGA_POOL_NOPOLL"))
+        keeper.t = std::thread([&]() {
+            (void)hipSetDevice(ctx->device);
+            while (!keeper.stop) {
+                (void)list_new_segments();
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            }
+        });
     // ---- the classic pool: one contiguous piece, cut into a part per slot; allocated when a classic launch is first needed
     uint64_t half_pool = 0;
     double classic_need = probe_mean * (double)n;  // estimated bytes of the problems that will run in classic mode (the whole call, or what chunk mode handed back)
@@ -612,6 +641,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             size_t free_b = 0, total_b = 0;
             (void)hipMemGetInfo(&free_b, &total_b);
             if (free_b < target + (4ull << 30)) {
+                std::lock_guard<std::mutex> list_lk(list_mu);  // (the keeper is not listing segments meanwhile)
                 W.stop_grower();
                 std::lock_guard<std::mutex> lk(W.mu);
                 for (auto &g : W.segs) (void)hipFree(g.p);
@@ -1060,16 +1090,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                     const hipError_t qe = hipStreamQuery(sarr[inflight[q].slot]);
                     if (qe != hipErrorNotReady) { pick = q; found = true; }  // finished (or failed: the synchronize below reports it)
                 }
-                if (!found) {
-                    if (n_arenas && !getenv("VGA_POOL_NOPOLL")) (void)list_new_segments();  // (segments the grower has finished meanwhile: their chunks join the free list)
-                    std::this_thread::sleep_for(std::chrono::microseconds(100));
-                }
-            }
-        }
-        if (n_arenas && inflight.size() == 1) {
-            while (!getenv("VGA_POOL_NOPOLL") && hipStreamQuery(sarr[inflight[0].slot]) == hipErrorNotReady) {
-                (void)list_new_segments();
-                std::this_thread::sleep_for(std::chrono::microseconds(200));
+                if (!found) std::this_thread::sleep_for(std::chrono::microseconds(100));
             }
         }
         const sub_t cur = inflight[pick];

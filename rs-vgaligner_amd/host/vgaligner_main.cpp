@@ -111,11 +111,6 @@ int map_main(int argc, char **argv)
     if (o.also_align && !m.count("graph")) throw Error("--also-align needs --graph (the reference unwraps it, map.rs:157)");
     bool exact = idx.size() >= 4 && idx.compare(idx.size() - 4, 4, ".idx") == 0;
     trace_mark("start");
-    Index ix = Index::load(exact ? idx : idx + ".idx");
-    trace_mark("index loaded");
-    std::vector<QuerySequence> reads = read_seqs_from_file(in);
-    trace_mark("reads parsed");
-    fprintf(stderr, "[vgaligner] Found %zu reads!\n", reads.size());
     if (m.count("devices") && m["devices"] == "all") o.all_devices = true;
     else if (m.count("devices")) {
         const std::string l = m["devices"];
@@ -129,6 +124,12 @@ int map_main(int argc, char **argv)
         }
         if (o.devices.empty()) throw Error("--devices needs a comma-separated list of GPU ids");
     }
+    prewarm_contexts(o);  // (HIP starts beside the reading of the index and the reads)
+    Index ix = Index::load(exact ? idx : idx + ".idx");
+    trace_mark("index loaded");
+    std::vector<QuerySequence> reads = read_seqs_from_file(in);
+    trace_mark("reads parsed");
+    fprintf(stderr, "[vgaligner] Found %zu reads!\n", reads.size());
     o.leave_contexts = !getenv("VGA_NO_FAST_EXIT");
     o.chunk_reads = std::stoull(opt(m, "chunk-reads", "32768"));
     o.keep_text = o.write_console || o.also_validate;

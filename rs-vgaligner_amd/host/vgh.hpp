@@ -99,6 +99,7 @@ std::string gaf_from_chain(const Index &ix, const QuerySequence &q, const vga_ma
 void gaf_from_chain_text(std::string &out, const Index &ix, const QuerySequence &q, const vga_map_result *m, uint64_t read, uint64_t chain,
                          const char *path, uint64_t path_len);
 std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a, uint64_t read);
+void gaf_from_alignment(std::string &out, const QuerySequence &q, const vga_align_result *a, uint64_t read);  // (appends)
 // ValidationRecord::from_graph_and_alignment + to_string (src/validate.rs:36-102) from one alignments-GAF line
 std::string validation_record(const Index &ix, const std::string &gaf_line, const std::vector<QuerySequence> &reads);
 
@@ -159,5 +160,8 @@ MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequen
 // concurrently; GAF order = read order (src/map.rs:123-133, 174-184).
 MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt,
                           const std::string &out_prefix);
+// Begins to create the contexts map_reads_multi(.., opt, ..) will use, on a thread of its own: starting HIP takes 0.1-0.3 s,
+// which a caller can spend reading its index and reads.  The next map_reads_multi call picks them up (and reports any error).
+void prewarm_contexts(const MapOptions &opt);
 
 }  // namespace vgh

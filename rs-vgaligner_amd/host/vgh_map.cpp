@@ -12,10 +12,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
+#include <future>
+#include <memory>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 
 namespace vgh {
 
@@ -137,13 +141,13 @@ void gaf_from_chain_text(std::string &out, const Index &ix, const QuerySequence 
     out += "\t0\t0\t0\t0\t0\t0\tta:Z:chain,n_anchors: "; put_u64(out, c1 - c0); out.push_back('\n');
 }
 
-std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a, uint64_t r)
+void gaf_from_alignment(std::string &out, const QuerySequence &q, const vga_align_result *a, uint64_t r)
 {
-    if (!a->aligned[r]) return gaf_placeholder(q);
+    if (!a->aligned[r]) { out += gaf_placeholder(q); return; }
     const char *cs = a->cs + a->cs_off[r], *cg = a->cigar + a->cigar_off[r];
     const size_t n_cs = strlen(cs), n_cg = strlen(cg);
-    std::string out;
-    out.reserve(q.name.size() + (a->path_off[r + 1] - a->path_off[r]) * 8 + n_cs + n_cg + 128);
+    const size_t need = out.size() + q.name.size() + (a->path_off[r + 1] - a->path_off[r]) * 8 + n_cs + n_cg + 128;
+    if (out.capacity() < need) out.reserve(std::max(need, 2 * out.capacity()));  // (records are appended: grow geometrically)
     // align.rs:1145-1167: qstart 0, qend len, '+', residue 0, mapq 255, literal "as:i:-30"
     out += q.name; out.push_back('\t'); put_u64(out, q.seq.size()); out += "\t0\t"; put_u64(out, q.seq.size()); out += "\t+\t";
     for (uint64_t t = a->path_off[r]; t < a->path_off[r + 1]; t++) {
@@ -154,6 +158,12 @@ std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a
     out.push_back('\t'); put_u64(out, a->path_length[r]); out.push_back('\t'); put_u64(out, a->path_start[r]);
     out.push_back('\t'); put_u64(out, a->path_end[r]); out += "\t0\t"; put_u64(out, a->block_length[r]);
     out += "\t255\tas:i:-30 "; out.append(cs, n_cs); out += ",cg:Z:"; out.append(cg, n_cg); out.push_back('\n');
+}
+
+std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a, uint64_t r)
+{
+    std::string out;
+    gaf_from_alignment(out, q, a, r);
     return out;
 }
 
@@ -245,25 +255,39 @@ std::vector<Shard> plan_shards(const std::vector<uint64_t> &len, uint32_t n_slot
 
 namespace {
 
-// GAF text of reads [0, n) built by several threads over contiguous ranges (the order of the reads is kept)
-template <typename F>
-std::string text_of_reads(uint64_t n, unsigned n_threads, F per_read)
+// GAF text of reads [0, n) built by several threads over contiguous ranges: the pieces, in read order
+// (size_of(r): an upper estimate of read r's text, so that a piece is allocated once; nullptr_t: none)
+template <typename F, typename S>
+std::vector<std::string> text_of_reads(uint64_t n, unsigned n_threads, F per_read, S size_of)
 {
     const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_threads, n / 64 + 1));
     std::vector<std::string> parts(T);
+    std::vector<std::string> errs(T);
     std::vector<std::thread> th;
     for (unsigned t = 0; t < T; t++)
         th.emplace_back([&, t]() {
-            const uint64_t a = n * t / T, b = n * (t + 1) / T;
-            for (uint64_t r = a; r < b; r++) per_read(r, parts[t]);
+            try {
+                const uint64_t a = n * t / T, b = n * (t + 1) / T;
+                if constexpr (!std::is_same<S, std::nullptr_t>::value) {
+                    size_t tot = 0;
+                    for (uint64_t r = a; r < b; r++) tot += size_of(r);
+                    parts[t].reserve(tot);
+                }
+                for (uint64_t r = a; r < b; r++) per_read(r, parts[t]);
+            } catch (const std::exception &e) { errs[t] = e.what(); if (errs[t].empty()) errs[t] = "error"; }
         });
     for (auto &x : th) x.join();
-    size_t tot = 0;
-    for (auto &q : parts) tot += q.size();
-    std::string out;
-    out.reserve(tot);
-    for (auto &q : parts) out += q;
-    return out;
+    for (auto &e : errs)
+        if (!e.empty()) throw Error(e);
+    return parts;
+}
+
+void append_pieces(std::string &dst, std::vector<std::string> &pieces)
+{
+    size_t tot = dst.size();
+    for (auto &q : pieces) tot += q.size();
+    dst.reserve(tot);
+    for (auto &q : pieces) { dst += q; std::string().swap(q); }
 }
 
 unsigned text_threads()
@@ -274,18 +298,25 @@ unsigned text_threads()
 }
 
 struct ChunkOut {
-    std::string chains, aligns;
+    std::vector<std::string> chains, aligns;  // GAF text in read order, in pieces
     uint64_t n_aligned = 0, n_anchors = 0, poa_cells = 0;
     double ms_map = 0, ms_align = 0;
 };
 
+// what the caller may do before map_chunk returns
+struct ChunkHooks {
+    std::function<void()> chains_ready;  // ChunkOut::chains is final (called from the chains thread)
+    std::function<void()> gpu_done;      // the chunk needs its context no longer (the alignments' text is still to be written)
+};
+
 // anchors -> chains -> (alignments) of reads [b, e) on one context; the GAF text of exactly those reads
-ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, uint64_t b0, uint64_t e0, const MapOptions &opt)
+void map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, uint64_t b0, uint64_t e0, const MapOptions &opt, ChunkOut &out,
+               const ChunkHooks &hooks)
 {
-    ChunkOut out;
     const uint64_t n = e0 - b0;
     const bool trace = getenv("VGA_TRACE") != nullptr;
-    auto t_prev = std::chrono::steady_clock::now();
+    const auto t_first = std::chrono::steady_clock::now();
+    auto t_prev = t_first;
     auto mark = [&](const char *what) {
         if (!trace) return;
         const auto t = std::chrono::steady_clock::now();
@@ -301,6 +332,7 @@ ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequenc
     for (uint64_t i = 0; i < n; i++) { concat += inputs[b0 + i].seq; off[i + 1] = concat.size(); }
     vga_batch *b = nullptr;
     if (vga_batch_create(ctx, concat.data(), off.data(), n, &b) != VGA_OK) throw Error(vga_last_error(ctx));
+    std::unique_ptr<vga_batch, void (*)(vga_batch *)> b_owner(b, vga_batch_destroy);
     vga_map_params mp;
     vga_map_default_params(&mp);
     mp.bandwidth = (uint32_t)opt.bandwidth;
@@ -308,32 +340,54 @@ ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequenc
     mp.chain_min_n_anchors = (uint32_t)opt.chain_min_n_anchors;
     mp.emit_dp = 0;  // the GAF writers read anchor coordinates and chain membership only
     vga_map_result *m = nullptr;
-    if (vga_map_batch(b, &mp, &m) != VGA_OK) { const std::string e = vga_last_error(ctx); vga_batch_destroy(b); throw Error(e); }
+    if (vga_map_batch(b, &mp, &m) != VGA_OK) throw Error(vga_last_error(ctx));
+    std::unique_ptr<vga_map_result, void (*)(vga_map_result *)> m_owner(m, vga_map_result_free);
     out.n_anchors = m->n_anchors;
     out.ms_map = m->ms_total;
     mark("batch + vga_map_batch");
-    // chains GAF (map.rs:123-145): every chain of every read, in order.  Text generation is host work that only reads the
-    // chains: it runs beside the alignment call, which keeps the GPU busy
+    // chains GAF (map.rs:123-145): every chain of every read, in order.  The path column of every chain is written by the GPU
+    // (K6) and the records are put together around it, on a thread beside the alignment call: K6 works on a stream of its own
+    // (include/vga_hip.h) and the rest only reads the chains
     const unsigned T = text_threads();
-    // the path column of every chain is written by the GPU (K6, before the alignment call takes it over); the records are
-    // put together around it on a host thread beside that call
-    vga_chain_text *ct = nullptr;
-    if (vga_chain_paths_text(ctx, m, &ct) != VGA_OK) { const std::string e = vga_last_error(ctx); vga_map_result_free(m); vga_batch_destroy(b); throw Error(e); }
-    mark("vga_chain_paths_text");
     std::string chain_err;
-    struct joiner {  // (an exception below must not leave the thread joinable: std::terminate)
-        std::thread &t;
-        ~joiner() { if (t.joinable()) t.join(); }
-    };
+    std::mutex k6_mu;
+    std::condition_variable k6_cv;
+    bool k6_done = false;
     std::thread chains_thread([&]() {
+        auto k6_finished = [&]() { { std::lock_guard<std::mutex> lk(k6_mu); k6_done = true; } k6_cv.notify_all(); };
         try {
+            const auto t0 = std::chrono::steady_clock::now();
+            vga_chain_text *ct = nullptr;
+            const int rc = vga_chain_paths_text(ctx, m, &ct);
+            const std::string e = rc != VGA_OK ? vga_last_error(ctx) : "";
+            k6_finished();
+            if (rc != VGA_OK) throw Error(e);
+            std::unique_ptr<vga_chain_text, void (*)(vga_chain_text *)> ct_owner(ct, vga_chain_text_free);
+            const auto t1 = std::chrono::steady_clock::now();
             out.chains = text_of_reads(n, opt.also_align ? std::max(1u, T / 2) : T, [&](uint64_t r, std::string &dst) {
                 for (uint64_t c = m->chain_off[r]; c < m->chain_off[r + 1]; c++)
                     gaf_from_chain_text(dst, ix, inputs[b0 + r], m, r, c, ct->text + ct->text_off[c], ct->text_off[c + 1] - ct->text_off[c]);
+            }, [&](uint64_t r) {
+                const uint64_t c0 = m->chain_off[r], c1 = m->chain_off[r + 1];
+                return (size_t)(ct->text_off[c1] - ct->text_off[c0]) + (size_t)(c1 - c0) * (inputs[b0 + r].name.size() + 128);
             });
-        } catch (const std::exception &e) { chain_err = e.what(); }
+            if (trace)
+                fprintf(stderr, "[vgh-trace] reads [%llu, %llu): (beside) vga_chain_paths_text %.3f ms, chains GAF text %.3f ms, ready %.3f ms after the chunk began\n",
+                        (unsigned long long)b0, (unsigned long long)e0, std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(),
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_first).count());
+            if (hooks.chains_ready) hooks.chains_ready();
+        } catch (const std::exception &e) {
+            chain_err = e.what();
+            if (chain_err.empty()) chain_err = "chains GAF text failed";
+            k6_finished();
+        }
     });
-    joiner chains_joiner{chains_thread};
+    struct joiner {  // (an exception below must not leave the thread joinable: std::terminate)
+        std::thread &t;
+        ~joiner() { if (t.joinable()) t.join(); }
+    } chains_joiner{chains_thread};
+    auto wait_k6 = [&]() { std::unique_lock<std::mutex> lk(k6_mu); k6_cv.wait(lk, [&]() { return k6_done; }); };
     if (opt.also_align) {
         vga_poa_params pp;
         vga_poa_default_params(&pp);
@@ -341,26 +395,32 @@ ChunkOut map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequenc
         vga_align_result *a = nullptr;
         if (vga_align_batch(b, m, (uint32_t)opt.align_best_n, &pp, &a) != VGA_OK) {
             const std::string e = vga_last_error(ctx);
-            chains_thread.join();
-            vga_chain_text_free(ct);
-            vga_map_result_free(m); vga_batch_destroy(b);
+            wait_k6();
             throw Error(e);
         }
+        std::unique_ptr<vga_align_result, void (*)(vga_align_result *)> a_owner(a, vga_align_result_free);
         out.ms_align = a->ms_total;
         out.poa_cells = a->poa_cells;
         mark("vga_align_batch");
-        out.aligns = text_of_reads(n, std::max(1u, T / 2), [&](uint64_t r, std::string &dst) { dst += gaf_from_alignment(inputs[b0 + r], a, r); });
+        // everything the text needs is in host memory now: the batch and, if the caller says so, the context can go
+        wait_k6();
+        b_owner.reset();
+        if (hooks.gpu_done) hooks.gpu_done();
+        out.aligns = text_of_reads(n, T, [&](uint64_t r, std::string &dst) { gaf_from_alignment(dst, inputs[b0 + r], a, r); },
+                                   [&](uint64_t r) {
+                                       return (size_t)(a->cs_off[r + 1] - a->cs_off[r]) + (size_t)(a->cigar_off[r + 1] - a->cigar_off[r]) +
+                                              (size_t)(a->path_off[r + 1] - a->path_off[r]) * 12 + inputs[b0 + r].name.size() + 160;
+                                   });
         for (uint64_t r = 0; r < n; r++) out.n_aligned += a->aligned[r];
-        vga_align_result_free(a);
         mark("alignments GAF text");
+    } else {
+        wait_k6();
+        b_owner.reset();
+        if (hooks.gpu_done) hooks.gpu_done();
     }
     chains_thread.join();
     mark("chains GAF text (joined)");
-    vga_chain_text_free(ct);
-    if (!chain_err.empty()) { vga_map_result_free(m); vga_batch_destroy(b); throw Error(chain_err); }
-    vga_map_result_free(m);
-    vga_batch_destroy(b);
-    return out;
+    if (!chain_err.empty()) throw Error(chain_err);
 }
 
 void check_aligner(const MapOptions &opt)
@@ -402,9 +462,10 @@ MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequen
     std::vector<uint64_t> len(inputs.size());
     for (size_t i = 0; i < inputs.size(); i++) len[i] = inputs[i].seq.size();
     for (const Shard &s : plan_shards(len, 1, opt.chunk_reads)) {
-        ChunkOut c = map_chunk(ctx, ix, inputs, s.begin, s.end, opt);
-        out.chains_gaf += c.chains;
-        out.alignments_gaf += c.aligns;
+        ChunkOut c;
+        map_chunk(ctx, ix, inputs, s.begin, s.end, opt, c, ChunkHooks());
+        append_pieces(out.chains_gaf, c.chains);
+        append_pieces(out.alignments_gaf, c.aligns);
         out.n_aligned += c.n_aligned; out.n_anchors += c.n_anchors; out.poa_cells += c.poa_cells;
         out.ms_map += c.ms_map; out.ms_align += c.ms_align;
         out.n_chunks++;
@@ -413,15 +474,12 @@ MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequen
     return out;
 }
 
-MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt, const std::string &out_prefix)
+namespace {
+
+// one context per device slot; with no list, every GPU vga_ctx_create accepts
+std::vector<vga_ctx *> create_contexts(const std::vector<int> &devs)
 {
-    check_aligner(opt);
-    trace_mark("map_reads_multi: start");
-    // one context per device slot; with no list, every GPU vga_ctx_create accepts
     std::vector<vga_ctx *> ctxs;
-    auto release = [&]() { for (vga_ctx *c : ctxs) vga_ctx_destroy(c); ctxs.clear(); };
-    std::vector<int> devs = opt.devices;
-    if (devs.empty() && !opt.all_devices) devs.push_back(opt.device);
     if (devs.empty()) {
         for (int d = 0; d < 64; d++) {
             vga_ctx *c = nullptr;
@@ -432,10 +490,56 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
     } else {
         for (int d : devs) {
             vga_ctx *c = nullptr;
-            if (vga_ctx_create(d, &c) != VGA_OK) { release(); throw Error("no MI355X device available: cannot create a context on device " + std::to_string(d) + " (this build has no CPU path)"); }
+            if (vga_ctx_create(d, &c) != VGA_OK) {
+                for (vga_ctx *x : ctxs) vga_ctx_destroy(x);
+                throw Error("no MI355X device available: cannot create a context on device " + std::to_string(d) + " (this build has no CPU path)");
+            }
             ctxs.push_back(c);
         }
     }
+    return ctxs;
+}
+
+std::vector<int> device_list(const MapOptions &opt)
+{
+    std::vector<int> devs = opt.devices;
+    if (devs.empty() && !opt.all_devices) devs.push_back(opt.device);
+    return devs;
+}
+
+std::mutex g_prewarm_mu;
+std::future<std::vector<vga_ctx *>> g_prewarm;
+std::vector<int> g_prewarm_devs;
+
+}  // namespace
+
+void prewarm_contexts(const MapOptions &opt)
+{
+    std::lock_guard<std::mutex> lk(g_prewarm_mu);
+    if (g_prewarm.valid()) return;
+    g_prewarm_devs = device_list(opt);
+    g_prewarm = std::async(std::launch::async, [devs = g_prewarm_devs]() { return create_contexts(devs); });
+}
+
+MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt, const std::string &out_prefix)
+{
+    check_aligner(opt);
+    trace_mark("map_reads_multi: start");
+    std::vector<vga_ctx *> ctxs;
+    auto release = [&]() { for (vga_ctx *c : ctxs) if (c) vga_ctx_destroy(c); ctxs.clear(); };
+    const std::vector<int> devs = device_list(opt);
+    {
+        std::unique_lock<std::mutex> lk(g_prewarm_mu);
+        if (g_prewarm.valid()) {  // contexts prewarm_contexts began to create (its error, if any, is thrown here)
+            std::future<std::vector<vga_ctx *>> f = std::move(g_prewarm);
+            const bool same = g_prewarm_devs == devs;
+            lk.unlock();
+            std::vector<vga_ctx *> got = f.get();
+            if (same) ctxs = std::move(got);
+            else for (vga_ctx *c : got) vga_ctx_destroy(c);
+        }
+    }
+    if (ctxs.empty()) ctxs = create_contexts(devs);
     const uint32_t n_slots = (uint32_t)ctxs.size();
     trace_mark("contexts created");
     // the two settings below travel to the library through the environment: what was there before comes back at the end
@@ -478,7 +582,7 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
     const bool stream = !opt.keep_text && !out_prefix.empty() && !same_file && !opt.also_validate;
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<uint8_t> done(plan.size(), 0);
+    std::vector<uint8_t> done(plan.size(), 0), chains_done(plan.size(), 0);
     bool abort_writer = false, abort_workers = false;
     std::string writer_err;
     std::thread writer;
@@ -491,17 +595,23 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
                     fa.open(out_prefix + "-alignments.gaf", std::ios::binary);
                     if (!fa) throw Error("Couldn't create file " + out_prefix + "-alignments.gaf");
                 }
+                auto put = [&](std::ofstream &f, std::vector<std::string> &pieces) {
+                    for (std::string &q : pieces) { f.write(q.data(), (std::streamsize)q.size()); std::string().swap(q); }
+                    if (!f) throw Error("Couldn't write the GAF files under " + out_prefix);
+                };
                 for (size_t i = 0; i < plan.size(); i++) {
+                    {  // the chains of a chunk are ready long before its alignments
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&]() { return chains_done[i] || done[i] || abort_writer; });
+                        if (!chains_done[i] && !done[i]) return;
+                    }
+                    put(fc, parts[i].chains);
                     {
                         std::unique_lock<std::mutex> lk(mu);
                         cv.wait(lk, [&]() { return done[i] || abort_writer; });
                         if (!done[i]) return;
                     }
-                    fc.write(parts[i].chains.data(), (std::streamsize)parts[i].chains.size());
-                    if (opt.also_align) fa.write(parts[i].aligns.data(), (std::streamsize)parts[i].aligns.size());
-                    if (!fc || (opt.also_align && !fa)) throw Error("Couldn't write the GAF files under " + out_prefix);
-                    std::string().swap(parts[i].chains);
-                    std::string().swap(parts[i].aligns);
+                    if (opt.also_align) put(fa, parts[i].aligns);
                 }
             } catch (const std::exception &e) {
                 writer_err = e.what();
@@ -509,6 +619,13 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
                 abort_workers = true;  // (nothing that is still to be mapped could be written)
             }
         });
+    // the last chunk of a slot: once its GPU work is done nothing needs the context any more.  A caller that is about to leave
+    // the process (leave_contexts) has it torn down right then, beside the text and file work that is left -- the driver
+    // takes about 5 ms per GB of pool to take the memory back, at hipFree or at exit alike
+    std::vector<size_t> last_of_slot(n_slots, plan.size());
+    for (size_t i = 0; i < plan.size(); i++) last_of_slot[plan[i].slot] = i;
+    std::vector<std::thread> destroyers;
+    std::mutex destroyers_mu;
     std::vector<std::thread> workers;
     for (uint32_t slot = 0; slot < n_slots; slot++)
         workers.emplace_back([&, slot]() {
@@ -516,7 +633,16 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
                 for (size_t i = 0; i < plan.size(); i++)
                     if (plan[i].slot == slot) {
                         { std::lock_guard<std::mutex> lk(mu); if (abort_workers) break; }
-                        parts[i] = map_chunk(ctxs[slot], ix, inputs, plan[i].begin, plan[i].end, opt);
+                        ChunkHooks hooks;
+                        if (stream) hooks.chains_ready = [&, i]() { { std::lock_guard<std::mutex> lk(mu); chains_done[i] = 1; } cv.notify_all(); };
+                        if (opt.leave_contexts && i == last_of_slot[slot])
+                            hooks.gpu_done = [&, slot]() {
+                                vga_ctx *c = ctxs[slot];
+                                ctxs[slot] = nullptr;
+                                std::lock_guard<std::mutex> lk(destroyers_mu);
+                                destroyers.emplace_back([c]() { vga_ctx_destroy(c); });
+                            };
+                        map_chunk(ctxs[slot], ix, inputs, plan[i].begin, plan[i].end, opt, parts[i], hooks);
                         { std::lock_guard<std::mutex> lk(mu); done[i] = 1; }
                         cv.notify_all();
                     }
@@ -530,6 +656,8 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
     trace_mark("chunks mapped and aligned");
     if (writer.joinable()) writer.join();
     trace_mark("GAF files written");
+    // (leave_contexts: whatever the tear-down threads have not finished, the exit of the process finishes)
+    for (std::thread &t : destroyers) t.detach();
     if (opt.leave_contexts) ctxs.clear();
     else release();
     trace_mark("contexts destroyed");
@@ -543,10 +671,8 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
     std::vector<double> ms_map(n_slots, 0.0), ms_align(n_slots, 0.0);
     for (size_t i = 0; i < plan.size(); i++) {  // read order
         if (!stream) {
-            out.chains_gaf += parts[i].chains;
-            out.alignments_gaf += parts[i].aligns;
-            std::string().swap(parts[i].chains);
-            std::string().swap(parts[i].aligns);
+            append_pieces(out.chains_gaf, parts[i].chains);
+            append_pieces(out.alignments_gaf, parts[i].aligns);
         }
         out.n_aligned += parts[i].n_aligned; out.n_anchors += parts[i].n_anchors; out.poa_cells += parts[i].poa_cells;
         ms_map[plan[i].slot] += parts[i].ms_map; ms_align[plan[i].slot] += parts[i].ms_align;

@@ -26,14 +26,32 @@ with tempfile.TemporaryDirectory(dir="/tmp") as d:
     t0 = time.perf_counter()
     subprocess.check_call([exe, "index", "-i", gfa, "-k", "11", "-o", os.path.join(d, "drb1")])
     t1 = time.perf_counter()
-    r = subprocess.run([exe, "map", "-i", os.path.join(d, "drb1"), "-f", fa, "-p", "abpoa", "-D", "-G", gfa, "-o", os.path.join(d, "out")] + extra,
-                       capture_output=True, text=True)
+    # (stderr is read line by line so that the trace marks "start" and "done" -- VGA_TRACE=1 -- get a time stamp of ours:
+    # what lies before the first and after the second is process start and exit)
+    no_align = os.environ.get("E2E_NO_ALIGN") == "1"  # (chains only: what the process costs without the alignment pass)
+    cmd = [exe, "map", "-i", os.path.join(d, "drb1"), "-f", fa, "-p", "abpoa"] + ([] if no_align else ["-D", "-G", gfa]) + ["-o", os.path.join(d, "out")] + extra
+    pr = subprocess.Popen(cmd, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
+    err_lines, t_start_mark, t_done_mark = [], None, None
+    for ln in pr.stderr:
+        now = time.perf_counter()
+        if "[vgh-trace] start " in ln:
+            t_start_mark = now
+        if "[vgh-trace] done " in ln:
+            t_done_mark = now
+        err_lines.append(ln)
+    rc = pr.wait()
     t2 = time.perf_counter()
-    sys.stderr.write(r.stderr)
-    assert r.returncode == 0, r.stderr
+    stderr_text = "".join(err_lines)
+    sys.stderr.write(stderr_text)
+    assert rc == 0, stderr_text
+
+    class r:  # (what the summary below reads)
+        stderr = stderr_text
     al = os.path.join(d, "out-alignments.gaf")
-    aligned = sum(1 for ln in open(al) if ln.split("\t")[5] != "*")
+    aligned = n if no_align else sum(1 for ln in open(al) if ln.split("\t")[5] != "*")
     print(json.dumps({"workload": os.environ.get("E2E_WORKLOAD", "config3"), "reads": n, "aligned": aligned, "index_s": round(t1 - t0, 2), "map_s": round(t2 - t1, 2),
                       "aligned_reads_per_s_end_to_end": round(aligned / (t2 - t1), 1),
+                      "before_main_s": None if t_start_mark is None else round(t_start_mark - t1, 3),
+                      "after_done_s": None if t_done_mark is None else round(t2 - t_done_mark, 3),
                       "chains_gaf_mb": round(os.path.getsize(os.path.join(d, "out-chains.gaf")) / 1e6, 1),
-                      "alignments_gaf_mb": round(os.path.getsize(al) / 1e6, 1), "flags": extra, "stderr_tail": r.stderr.strip().splitlines()[-4:]}))
+                      "alignments_gaf_mb": 0 if no_align else round(os.path.getsize(al) / 1e6, 1), "flags": extra, "stderr_tail": r.stderr.strip().splitlines()[-4:]}))
