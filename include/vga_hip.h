@@ -239,6 +239,12 @@ typedef struct {
 int vga_align_batch(vga_batch *b, const vga_map_result *chains, uint32_t align_best_n,
                     const vga_poa_params *params, vga_align_result **out);
 void vga_align_result_free(vga_align_result *r);
+/* Optional, returns at once.  The first vga_align_batch of a context allocates its traceback memory before its first kernel
+ * (tens of GB of HBM; on memory another process has used the driver clears what it hands out, 0.2 s and more).  A caller that
+ * knows it is going to align n_reads reads of up to max_read_len bases says so early -- before vga_map_batch, say -- and the
+ * allocation runs on a thread of its own meanwhile.  No counterpart in the reference (its abPOA allocates per call on the
+ * host, src/align.rs:1032-1040). */
+int vga_align_prepare(vga_ctx *ctx, uint64_t n_reads, uint32_t max_read_len);
 
 /* Per-kernel timing of the most recent vga_map_batch / vga_poa_batch / vga_align_batch on this ctx:
  * name[i] / total milliseconds / launches, measured with hipEvents on the stream each launch ran on.

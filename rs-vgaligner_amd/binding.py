@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "vga_index_upload", "vga_batch_create", "vga_batch_destroy", "vga_map_default_params", "vga_map_batch",
     "vga_map_result_free", "vga_poa_default_params", "vga_poa_result_free", "vga_poa_batch", "vga_align_batch",
     "vga_align_result_free", "vga_last_kernel_times", "vga_chain_paths_text", "vga_chain_text_free",
+    "vga_align_prepare",
 ]
 
 
@@ -140,6 +141,8 @@ def load_library():
     L.vga_align_result_free.argtypes = [_P(AlignResult)]
     L.vga_last_kernel_times.argtypes = [vp, _P(KernelTime), C.c_int]
     L.vga_chain_paths_text.argtypes = [vp, _P(MapResult), _P(_P(ChainText))]
+    L.vga_align_prepare.argtypes = [vp, C.c_uint64, C.c_uint32]
+    L.vga_align_prepare.restype = C.c_int
     L.vga_chain_text_free.argtypes = [_P(ChainText)]
     _lib = L
     return L
@@ -444,6 +447,10 @@ class Context:
                                          _u32p(esa), _u32p(eda), _u64p(query_off), "".join(qs).encode(), C.byref(p),
                                          C.byref(out)))
         return PoaOut(self.L, out)
+
+    def align_prepare(self, n_reads: int, max_read_len: int) -> None:
+        """vga_align_prepare: start allocating what the first align_batch of this context will need (returns at once)"""
+        self._check(self.L.vga_align_prepare(self.h, int(n_reads), int(max_read_len)))
 
     def chain_paths_text(self, chains: "MapOut") -> List[bytes]:
         """the path column of every chain's GAF record (vga_chain_paths_text), one bytes object per chain"""

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <chrono>
 #include <cstdarg>
@@ -15,7 +16,7 @@
 
 #include "../../include/vga_hip.h"
 
-#define VGA_ABI_VERSION 4
+#define VGA_ABI_VERSION 5
 
 struct vga_dev_index {
     uint32_t k = 0;
@@ -131,26 +132,48 @@ struct vga_dbuf {
     ~vga_dbuf() { release(); }
 };
 
-// pinned, grow-only host staging buffer
+// pinned, grow-only host staging buffer.  Large ones are anonymous huge-page memory registered with the runtime: pinning what
+// the process already owns costs a quarter of a hipHostMalloc of the same size (17 against 60-90 ms per 400 MB,
+// tests/microbench/pinned_time.hip) and copies run at the same rate -- a process that aligns one batch and exits (the CLI)
+// spent 0.2 s of its 2 s in those allocations.
 template <typename T>
 struct vga_hbuf {
     T *p = nullptr;
     size_t cap = 0;
+    size_t mapped = 0;  // bytes of the registered mapping (0: p came from hipHostMalloc)
+    void release()
+    {
+        if (p && mapped) { (void)hipHostUnregister(p); (void)munmap(p, mapped); }
+        else if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        mapped = 0;
+    }
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = n + n / 8 + 64;
+        release();
+        const size_t want = n + n / 8 + 64;
+        const size_t bytes = (want * sizeof(T) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        if (bytes >= ((size_t)8 << 20)) {
+            void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q != MAP_FAILED) {
+                (void)madvise(q, bytes, MADV_HUGEPAGE);
+                if (hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) {
+                    p = (T *)q;
+                    cap = want;
+                    mapped = bytes;
+                    return hipSuccess;
+                }
+                (void)hipGetLastError();
+                (void)munmap(q, bytes);
+            }
+        }
         hipError_t e = hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault);
         if (e == hipSuccess) cap = want;
         return e;
     }
-    ~vga_hbuf()
-    {
-        if (p) (void)hipHostFree(p);
-    }
+    ~vga_hbuf() { release(); }
 };
 
 // host-side phase tracing (VGA_TRACE=1): prints wall-clock deltas to stderr

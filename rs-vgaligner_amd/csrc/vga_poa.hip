@@ -220,7 +220,7 @@ struct poa_ws {
     // chunk pool (device side)
     vga_dbuf<unsigned long long> d_head;  // the free-list heads (POA_LISTS of them, a cache line apart), then the statistics
     vga_dbuf<uint32_t> d_next_chunk, d_slot_flag;
-    vga_hbuf<unsigned long long> h_empties; // where the keeper reads poa_chunk_pool::stats[0] to
+    vga_hbuf<uint32_t> h_short;           // poa_chunk_pool::short_flag
     vga_hbuf<uint64_t> h_seg_base;        // staging of ...
     vga_dbuf<uint64_t> d_seg_base;        // ... the segment table the kernels read (an entry is copied before its chunks are listed)
     hipStream_t add_stream = nullptr;
@@ -235,6 +235,27 @@ struct poa_ws {
         for (int l = 0; l < POA_LISTS; l++) init[(size_t)l * POA_LIST_STRIDE] = (unsigned long long)POA_NIL;
         return hipMemcpy(d_head.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
     }
+    // vga_align_prepare: the state regions and the first segments, allocated on a thread of its own before the first
+    // vga_align_batch call needs them (on memory another process used the driver clears what it hands out: 13 GB = 0.2 s)
+    std::thread preparer;
+    void prepare_async(uint64_t state_want, uint64_t pool_want)
+    {
+        join_preparer();
+        preparer = std::thread([this, state_want, pool_want]() {
+            (void)hipSetDevice(device);
+            if (state_bytes < state_want) {
+                uint8_t *q = nullptr;
+                if (hipMalloc((void **)&q, state_want) == hipSuccess) {
+                    if (state) (void)hipFree(state);
+                    state = q;
+                    state_bytes = state_want;
+                } else
+                    (void)hipGetLastError();  // (poa_run asks again, and reports)
+            }
+            if (pool_want) request(pool_want);
+        });
+    }
+    void join_preparer() { if (preparer.joinable()) preparer.join(); }
     void stop_grower()
     {
         { std::lock_guard<std::mutex> lk(mu); grow_target = 0; }
@@ -242,6 +263,7 @@ struct poa_ws {
     }
     ~poa_ws()
     {
+        join_preparer();
         stop_grower();
         for (auto &g : segs) (void)hipFree(g.p);
         if (classic) (void)hipFree(classic);
@@ -307,6 +329,51 @@ template <typename F>
 void parallel_for(uint64_t n, F f) { vga_parallel_for(n, f); }
 
 }  // namespace
+
+// bytes of one state region of chunk-pool mode: the value-row ring, the wide-row scratch and a few kept value rows of a
+// problem whose query has max_q bases
+static uint64_t poa_state_size(uint32_t max_q)
+{
+    const uint64_t maxrow_all = (6ull * (uint64_t)((max_q + 8) & ~3u) + 15ull) & ~15ull;
+    return (maxrow_all * (POA_RING_SPAN + 1) + 12ull * poa_lds_cols(max_q) + 4096ull + 65535ull) & ~65535ull;
+}
+
+// include/vga_hip.h.  Optional: what the first vga_align_batch call would allocate before its first kernel -- the state regions
+// and about half of the chunk segments it is going to ask for -- starts to be allocated now, on a thread of its own.
+extern "C" int vga_align_prepare(vga_ctx *ctx, uint64_t n_reads, uint32_t max_read_len)
+{
+    if (!ctx) return VGA_ERR_ARG;
+    if (n_reads == 0 || max_read_len == 0 || max_read_len >= (1u << 24)) return VGA_OK;
+    if (getenv("VGA_POA_ARENAS") && atoi(getenv("VGA_POA_ARENAS")) == 0) return VGA_OK;  // (classic mode sizes its pool itself)
+    if (4ull * ((uint64_t)max_read_len + 8) > POA_CHUNK) return VGA_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return vga_set_error(ctx, VGA_ERR_HIP, "vga_align_prepare: hipSetDevice failed");
+    if (!ctx->poa_ws) {
+        ctx->poa_ws = new poa_ws();
+        ctx->poa_ws_free = [](void *q) { delete (poa_ws *)q; };
+    }
+    poa_ws &W = *(poa_ws *)ctx->poa_ws;
+    W.device = ctx->device;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return VGA_OK;
+    uint64_t avail = free_b > (16ull << 30) ? (uint64_t)((double)free_b * 0.85) : free_b / 4;
+    if (const char *fr = getenv("VGA_POOL_FRACTION")) {
+        const double f = atof(fr);
+        if (f > 0.0 && f < 1.0) avail = (uint64_t)((double)avail * f);
+    }
+    if (const char *env_pool = getenv("VGA_POOL_BYTES")) avail = std::min<uint64_t>(avail, strtoull(env_pool, nullptr, 10));
+    const uint64_t state_size = poa_state_size(max_read_len);
+    uint64_t ns = std::min<uint64_t>(16ull * (uint64_t)ctx->n_cu, std::max<uint64_t>(n_reads, 64));
+    while (ns > 1 && ns * state_size > avail / 4) ns /= 2;
+    if (ns * state_size > avail / 2) return VGA_OK;
+    // the direction rows of a read of L bases against its subgraph: about 1.7 L rows of a band about 0.25 L wide plus the kept
+    // value rows -- half of what the resident problems of such a call will hold (poa_run asks for the rest, from its probe)
+    const double per_problem = 0.5 * (double)max_read_len * (double)max_read_len + 2.0 * (double)POA_CHUNK;
+    const uint64_t resident = std::min<uint64_t>(n_reads, 6ull * (uint64_t)ctx->n_cu);
+    uint64_t pool_want = (uint64_t)std::min<double>((double)resident * per_problem * 0.35, (double)avail / 4.0) & ~(POA_CHUNK - 1);
+    if (pool_want < 16 * POA_CHUNK) pool_want = 0;
+    W.prepare_async(ns * state_size, pool_want);
+    return VGA_OK;
+}
 
 int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vector<poa_item> &out, poa_timing &tm)
 {
@@ -436,6 +503,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         ctx->poa_ws_free = [](void *q) { delete (poa_ws *)q; };
     }
     poa_ws &W = *(poa_ws *)ctx->poa_ws;
+    W.join_preparer();
 #define POA_CHECK(call)                                                                              \
     do {                                                                                             \
         hipError_t e_ = (call);                                                                      \
@@ -492,8 +560,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     // chunk-pool mode (k_poa_dp_t5 with its fused traceback; VGA_POA_ARENAS=0 switches it off): every row of a problem must
     // fit a chunk (a multi-predecessor row has four planes), and a state region holds the ring, the scratch rows and a few
     // kept value rows
-    const uint64_t maxrow_all = (6ull * (uint64_t)((max_q + 8) & ~3u) + 15ull) & ~15ull;
-    const uint64_t state_size = (maxrow_all * (POA_RING_SPAN + 1) + 12ull * poa_lds_cols(max_q) + 4096ull + 65535ull) & ~65535ull;
+    const uint64_t state_size = poa_state_size(max_q);
     const bool arena_wanted = t5_k && tb_fused && !(getenv("VGA_POA_ARENAS") && atoi(getenv("VGA_POA_ARENAS")) == 0) &&
                               4ull * ((uint64_t)max_q + 8) <= POA_CHUNK;
     // classic mode: two sub-batches in flight (three are no faster, four overflow their pool quarters).  Arena mode: the
@@ -545,9 +612,12 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 { std::lock_guard<std::mutex> lk(W.mu); have = W.pool_size; }
                 if (have < want && free_b < want - have + (8ull << 30)) { (void)hipFree(W.classic); W.classic = nullptr; W.classic_size = 0; }
             }
-            W.seg_bytes = std::min<uint64_t>(1ull << POA_SEG_LOG2, std::max<uint64_t>(want, 16 * POA_CHUNK));
-            if (const char *e = getenv("VGA_POOL_SEG")) W.seg_bytes = std::max<uint64_t>(16 * POA_CHUNK, strtoull(e, nullptr, 10) & ~(POA_CHUNK - 1));
-            W.seg_bytes = std::min<uint64_t>(W.seg_bytes, 1ull << POA_SEG_LOG2);  // (chunks are numbered segment << 12 | chunk in segment)
+            {
+                std::lock_guard<std::mutex> lk(W.mu);  // (the grower may be at work already: vga_align_prepare)
+                W.seg_bytes = std::min<uint64_t>(1ull << POA_SEG_LOG2, std::max<uint64_t>(want, 16 * POA_CHUNK));
+                if (const char *e = getenv("VGA_POOL_SEG")) W.seg_bytes = std::max<uint64_t>(16 * POA_CHUNK, strtoull(e, nullptr, 10) & ~(POA_CHUNK - 1));
+                W.seg_bytes = std::min<uint64_t>(W.seg_bytes, 1ull << POA_SEG_LOG2);  // (chunks are numbered segment << 12 | chunk in segment)
+            }
             W.request(want);
             const uint64_t got = W.wait_for(std::min<uint64_t>(want, W.seg_bytes));
             if (got >= 16 * POA_CHUNK) {
@@ -556,7 +626,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 POA_CHECK(W.d_next_chunk.reserve(max_chunks));
                 POA_CHECK(W.d_slot_flag.reserve(16ull * (uint64_t)ctx->n_cu + 64));
                 POA_CHECK(W.h_seg_base.reserve(POA_MAX_SEGS));
-                POA_CHECK(W.h_empties.reserve(1));
+                POA_CHECK(W.h_short.reserve(16));
+                W.h_short.p[0] = 0;
                 POA_CHECK(W.d_seg_base.reserve(POA_MAX_SEGS));
                 if (!W.add_stream) {
                     POA_CHECK(hipStreamCreateWithFlags(&W.add_stream, hipStreamNonBlocking));
@@ -567,6 +638,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 CP.head = W.d_head.p; CP.next = W.d_next_chunk.p; CP.seg_base = W.d_seg_base.p;
                 CP.cps_log2 = POA_SEG_LOG2 - 20; CP.n_slots = n_arenas; CP.state_base = W.state; CP.state_size = state_size;
                 CP.slot_flag = W.d_slot_flag.p; CP.stats = W.d_head.p + POA_LISTS * POA_LIST_STRIDE;
+                CP.short_flag = W.h_short.p;
             }
         }
     }
@@ -590,22 +662,20 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             if (tr.on && W.segs_listed > 1) fprintf(stderr, "[vga-trace] poa: segment %zu listed (%u chunks)\n", W.segs_listed, cnt);
         }
         hipError_t e = fresh.empty() ? hipSuccess : hipStreamSynchronize(W.add_stream);
-        // requests that found the list empty: the pool is short of what the resident workgroups need -- more segments
-        if (e == hipSuccess && ++W.polls % 4 == 0) {
-            unsigned long long *empties = W.h_empties.p;
-            e = hipMemcpyAsync(empties, W.d_head.p + POA_LISTS * POA_LIST_STRIDE, sizeof *empties, hipMemcpyDeviceToHost, W.add_stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(W.add_stream);
-            // (one step at a time: what is counted while a step is still being allocated and listed is the shortage that
-            // step answers -- without this the target runs away, +50 % every few milliseconds)
-            bool settled;
-            { std::lock_guard<std::mutex> lk(W.mu); settled = !W.growing && W.segs_listed == W.segs.size(); }
-            if (e == hipSuccess && !settled) W.empties_seen = std::max<uint64_t>(W.empties_seen, *empties);
-            if (e == hipSuccess && settled && *empties > W.empties_seen) {
-                W.empties_seen = *empties;
+        // requests that found the list empty: the pool is short of what the resident workgroups need -- more segments.
+        // (The kernels raise a flag in pinned host memory: reading it costs no GPU work.)
+        volatile uint32_t *flag = W.h_short.p;
+        // one step at a time: what is raised while a step is still being allocated and listed is the shortage that step
+        // answers -- without this the target runs away, +50 % every few milliseconds
+        bool settled;
+        { std::lock_guard<std::mutex> lk(W.mu); settled = !W.growing && W.segs_listed == W.segs.size(); }
+        if (e == hipSuccess && *flag) {
+            *flag = 0;
+            if (settled) {
                 uint64_t ps; { std::lock_guard<std::mutex> lk(W.mu); ps = std::max(W.pool_size, W.grow_target); }
                 const uint64_t more = std::min<uint64_t>(ps + ps / 2 + (4ull << 30), avail_pool);
                 if (more > ps) W.request(more);
-                if (tr.on) fprintf(stderr, "[vga-trace] poa: %llu requests have found every free list empty so far: pool target %.1f -> %.1f GB\n", *empties, (double)ps / 1e9, (double)more / 1e9);
+                if (tr.on) fprintf(stderr, "[vga-trace] poa: requests have found every free list empty: pool target %.1f -> %.1f GB\n", (double)ps / 1e9, (double)more / 1e9);
             }
         }
         return e;
@@ -691,7 +761,12 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             const int rcc = ensure_classic();
             if (rcc != VGA_OK) { dev_failed = true; dev_rc = rcc; return {i0, i0, 0.0, slot, 0}; }
         }
+        const auto t_launch0 = std::chrono::steady_clock::now();
+        auto lt = [&](const char *what) {  // (VGA_TRACE: where the host's time goes between a launch ending and the next one starting)
+            if (tr.on) fprintf(stderr, "[vga-trace] poa:     launch set-up: %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_launch0).count());
+        };
         if (arena && launch_err == hipSuccess) launch_err = list_new_segments();
+        lt("free lists looked after");
         uint8_t *pool_base = arena ? nullptr : W.classic + (uint64_t)slot * half_pool;
         const double budget = (double)half_pool * 0.92;
         double used_est = 0, raw_est = 0, cells_est = 0;
@@ -715,6 +790,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             cells_est += (double)G[order[i1]].N * estw[order[i1]];
             i1++;
         }
+        lt("problems chosen (and prepared)");
         auto chk = [&](hipError_t e) { if (e != hipSuccess && launch_err == hipSuccess) launch_err = e; };
         bool sub_t4 = false;   // ... k_poa_dp_t4 (its own direction-byte encoding)
         bool sub_t5 = false;   // ... k_poa_dp_t5 (direction dwords)
@@ -758,6 +834,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         chk(S.d_rows.reserve(tot_rows)); chk(S.d_outs.reserve(nb)); chk(S.d_ops.reserve(tot_ops)); chk(S.d_orow.reserve(tot_ops));
         if (dev) chk(S.d_ids.reserve(2 * (size_t)nb));
         if (launch_err != hipSuccess) return {i0, i0, 0.0, slot, 0};
+        lt("buffers reserved");
         if (dev) {
             // the graphs are in the device store: one workgroup per problem copies its pieces into this slot's buffers
             for (uint32_t t = 0; t < nb; t++) {
@@ -792,6 +869,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             chk(hipMemcpyAsync(S.d_q.p, S.h_q.p, tot_q, hipMemcpyHostToDevice, st));
         }
         chk(hipMemsetAsync(W.d_next.p + slot, 0, sizeof(unsigned long long), st));
+        lt("graphs staged");
         int t_dp = vga_timer_begin(ctx, "poa_band_dp", 0, st);
         {
             uint32_t mq = 0;
@@ -878,8 +956,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 while (nt > 128 && lds_of(nt) > lds_limit) nt /= 2;
             const size_t lds = lds_of(nt);
             if (tr.on)
-                fprintf(stderr, "[vga-trace] poa: launch %u problems, NT %d, %s, window %u of %u columns, width estimate mean %.0f max %.0f, LDS %zu B\n",
-                        nb, nt, t5 ? "k_poa_dp_t5" : (t4 ? "k_poa_dp_t4" : "k_poa_dp_lds"), hg_cols, lds_cols, mean_w, mw, lds);
+                fprintf(stderr, "[vga-trace] poa: (at %.1f ms) launch %u problems, NT %d, %s, window %u of %u columns, width estimate mean %.0f max %.0f, LDS %zu B\n",
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), nb, nt,
+                        t5 ? "k_poa_dp_t5" : (t4 ? "k_poa_dp_t4" : "k_poa_dp_lds"), hg_cols, lds_cols, mean_w, mw, lds);
             (void)hipGetLastError();  // a launch failure below must be this launch's, not an older ignored status
 #define POA_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_sink.p, P, S.d_rows.p, pool_base,          \
                  W.d_next.p + slot, half_pool, S.d_outs.p, lds_cols
@@ -1098,6 +1177,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         {
             const hipError_t se = hipStreamSynchronize(sarr[cur.slot]);
             if (se != hipSuccess) { launch_err = se; break; }  // (falls through to the drain of every stream below)
+            if (tr.on) fprintf(stderr, "[vga-trace] poa: (at %.1f ms) the launch of [%llu, %llu) has finished\n",
+                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), (unsigned long long)cur.i0, (unsigned long long)cur.i1);
         }
         const poa_slot::out_set &S = W.slot[cur.slot].outs[cur.oset];
         if (launch_err != hipSuccess) break;
@@ -1171,8 +1252,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                                 "%.0f %% of them in kept rows, query %u\n", (double)worst_t / 1e5, g.N, (double)worst_t / 100.0 / (double)std::max(1u, g.N),
                         g.n_ntab - 1, (double)ho.cells / 1e6, (double)ho.cells / (double)std::max(1u, g.N), ho.maxw, 100.0 * (double)ho.vcells / (double)std::max<uint64_t>(1, ho.cells), g.qlen);
             }
-            fprintf(stderr, "[vga-trace] poa: sub-batch [%llu, %llu) done, pool %.1f GB, widest row %u columns, worst width / estimate %.3f; "
+            fprintf(stderr, "[vga-trace] poa: (at %.1f ms) sub-batch [%llu, %llu) done, pool %.1f GB, widest row %u columns, worst width / estimate %.3f; "
                             "DP %.1f ms, mean %.1f workgroups resident, on GPU clock %.3f .. %.3f s\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(),
                     (unsigned long long)cur.i0, (unsigned long long)cur.i1, (double)W.h_next.p[cur.slot] / 1e9, mx, worst,
                     te > tb ? (double)(te - tb) / 1e5 : 0.0, te > tb ? (double)tsum / (double)(te - tb) : 0.0, (double)(tb % 100000000000ull) / 1e8,
                     (double)(te % 100000000000ull) / 1e8);
@@ -1208,7 +1290,12 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         fill();
         {
             const uint64_t a0 = cur.i0, cnt = cur.i1 - cur.i0;
+            const auto t_post0 = std::chrono::steady_clock::now();
             parallel_for(cnt, [&](uint64_t t) { post_one(S, a0, a0 + t); });
+            if (tr.on)
+                fprintf(stderr, "[vga-trace] poa:   CIGAR / cs strings of sub-batch [%llu, %llu): %.1f ms on the host, %zu launches in flight meanwhile, at %.1f ms\n",
+                        (unsigned long long)cur.i0, (unsigned long long)cur.i1, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_post0).count(),
+                        inflight.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count());
             for (uint64_t i = cur.i0; i < cur.i1; i++) {
                 const poa_out &ho = S.h_outs.p[i - cur.i0];
                 if (ho.status == POA_ST_POOL || ho.status == POA_ST_RETRY) continue;

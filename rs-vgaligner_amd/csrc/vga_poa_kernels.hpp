@@ -118,6 +118,8 @@ struct poa_chunk_pool {
     uint64_t state_size;
     uint32_t *slot_flag;         // 0 free / 1 taken
     unsigned long long *stats;   // [0] requests that found every list empty (the host adds segments when it grows)
+    uint32_t *short_flag;        // pinned host memory: set to 1 with stats[0] -- the host's keeper thread reads (and clears) it
+                                 // without any GPU work of its own (a copy of stats[0] waited 0.1-0.2 s for a slot on a full GPU)
 };
 __device__ __forceinline__ uint64_t poa_chunk_addr(const poa_chunk_pool &C, uint32_t idx)
 {
@@ -138,7 +140,10 @@ __device__ __forceinline__ uint32_t poa_chunk_pop(const poa_chunk_pool &C, uint3
                 if (atomicCAS(hd, h, ((h >> 32) + 1ull) << 32 | nx) == h) return idx;
             }
         }
-        if (round == 0) (void)atomicAdd(C.stats, 1ull);
+        if (round == 0) {
+            (void)atomicAdd(C.stats, 1ull);
+            __hip_atomic_store(C.short_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         __builtin_amdgcn_s_sleep(127);
     }
     return POA_NIL;

@@ -139,6 +139,14 @@ int map_main(int argc, char **argv)
     if (o.also_align) fprintf(stderr, "[vgaligner] Alignment took: %.0f ms; Found %llu alignments!\n", out.ms_align, (unsigned long long)out.n_reads);
     if (o.write_console) fputs(o.also_align ? out.alignments_gaf.c_str() : out.chains_gaf.c_str(), stdout);
     trace_mark("done");
+    if (getenv("VGA_TRACE"))  // (what the exit has to give back: resident host memory)
+        if (FILE *f = fopen("/proc/self/status", "r")) {
+            char ln[256];
+            while (fgets(ln, sizeof ln, f))
+                if (!strncmp(ln, "VmRSS", 5) || !strncmp(ln, "VmHWM", 5) || !strncmp(ln, "RssAnon", 7) || !strncmp(ln, "RssShmem", 8) || !strncmp(ln, "RssFile", 7))
+                    fprintf(stderr, "[vgh-trace] %s", ln);
+            fclose(f);
+        }
     if (o.leave_contexts) {  // the GAF files are closed; what is left is HBM the driver reclaims by itself
         fflush(stdout);
         fflush(stderr);

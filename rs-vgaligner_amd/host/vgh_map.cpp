@@ -141,23 +141,48 @@ void gaf_from_chain_text(std::string &out, const Index &ix, const QuerySequence 
     out += "\t0\t0\t0\t0\t0\t0\tta:Z:chain,n_anchors: "; put_u64(out, c1 - c0); out.push_back('\n');
 }
 
+namespace {
+// decimal digits through a raw pointer (the records are tens of kilobytes of small numbers: std::string::push_back per
+// character, with its capacity check, is what the text threads would spend their time in)
+inline char *put_u64_raw(char *p, uint64_t v)
+{
+    char t[24];
+    int n = 0;
+    do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = t[--n];
+    return p;
+}
+inline char *put_str_raw(char *p, const char *s, size_t n) { memcpy(p, s, n); return p + n; }
+}  // namespace
+
 void gaf_from_alignment(std::string &out, const QuerySequence &q, const vga_align_result *a, uint64_t r)
 {
     if (!a->aligned[r]) { out += gaf_placeholder(q); return; }
     const char *cs = a->cs + a->cs_off[r], *cg = a->cigar + a->cigar_off[r];
     const size_t n_cs = strlen(cs), n_cg = strlen(cg);
-    const size_t need = out.size() + q.name.size() + (a->path_off[r + 1] - a->path_off[r]) * 8 + n_cs + n_cg + 128;
-    if (out.capacity() < need) out.reserve(std::max(need, 2 * out.capacity()));  // (records are appended: grow geometrically)
+    const size_t n_path = (size_t)(a->path_off[r + 1] - a->path_off[r]);
+    // an upper bound of the record (a path step is '>' and the digits of at most the largest id), written in place and cut to
+    // what was used
+    uint64_t max_id = 0;
+    for (uint64_t t = a->path_off[r]; t < a->path_off[r + 1]; t++) max_id = std::max<uint64_t>(max_id, id_of(a->path_handles[t]));
+    size_t step = 2;
+    for (uint64_t v = max_id; v >= 10; v /= 10) step++;
+    const size_t old = out.size(), bound = q.name.size() + n_path * step + n_cs + n_cg + 256;
+    if (out.capacity() < old + bound) out.reserve(std::max(old + bound, 2 * out.capacity()));  // (records are appended: grow geometrically)
+    out.resize(old + bound);
+    char *p = &out[old];
     // align.rs:1145-1167: qstart 0, qend len, '+', residue 0, mapq 255, literal "as:i:-30"
-    out += q.name; out.push_back('\t'); put_u64(out, q.seq.size()); out += "\t0\t"; put_u64(out, q.seq.size()); out += "\t+\t";
+    p = put_str_raw(p, q.name.data(), q.name.size()); *p++ = '\t'; p = put_u64_raw(p, q.seq.size()); p = put_str_raw(p, "\t0\t", 3);
+    p = put_u64_raw(p, q.seq.size()); p = put_str_raw(p, "\t+\t", 3);
     for (uint64_t t = a->path_off[r]; t < a->path_off[r + 1]; t++) {
         const Handle h = a->path_handles[t];
-        out.push_back(is_rev(h) ? '<' : '>');
-        put_u64(out, id_of(h));
+        *p++ = is_rev(h) ? '<' : '>';
+        p = put_u64_raw(p, id_of(h));
     }
-    out.push_back('\t'); put_u64(out, a->path_length[r]); out.push_back('\t'); put_u64(out, a->path_start[r]);
-    out.push_back('\t'); put_u64(out, a->path_end[r]); out += "\t0\t"; put_u64(out, a->block_length[r]);
-    out += "\t255\tas:i:-30 "; out.append(cs, n_cs); out += ",cg:Z:"; out.append(cg, n_cg); out.push_back('\n');
+    *p++ = '\t'; p = put_u64_raw(p, a->path_length[r]); *p++ = '\t'; p = put_u64_raw(p, a->path_start[r]);
+    *p++ = '\t'; p = put_u64_raw(p, a->path_end[r]); p = put_str_raw(p, "\t0\t", 3); p = put_u64_raw(p, a->block_length[r]);
+    p = put_str_raw(p, "\t255\tas:i:-30 ", 14); p = put_str_raw(p, cs, n_cs); p = put_str_raw(p, ",cg:Z:", 6); p = put_str_raw(p, cg, n_cg); *p++ = '\n';
+    out.resize((size_t)(p - out.data()));
 }
 
 std::string gaf_from_alignment(const QuerySequence &q, const vga_align_result *a, uint64_t r)
@@ -333,6 +358,11 @@ void map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &
     vga_batch *b = nullptr;
     if (vga_batch_create(ctx, concat.data(), off.data(), n, &b) != VGA_OK) throw Error(vga_last_error(ctx));
     std::unique_ptr<vga_batch, void (*)(vga_batch *)> b_owner(b, vga_batch_destroy);
+    if (opt.also_align) {  // the traceback memory of the alignment call begins to be allocated beside the chaining
+        uint64_t longest = 0;
+        for (uint64_t i = 0; i < n; i++) longest = std::max<uint64_t>(longest, inputs[b0 + i].seq.size());
+        if (longest < (1u << 24)) (void)vga_align_prepare(ctx, n, (uint32_t)longest);
+    }
     vga_map_params mp;
     vga_map_default_params(&mp);
     mp.bandwidth = (uint32_t)opt.bandwidth;
@@ -409,7 +439,7 @@ void map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &
         out.aligns = text_of_reads(n, T, [&](uint64_t r, std::string &dst) { gaf_from_alignment(dst, inputs[b0 + r], a, r); },
                                    [&](uint64_t r) {
                                        return (size_t)(a->cs_off[r + 1] - a->cs_off[r]) + (size_t)(a->cigar_off[r + 1] - a->cigar_off[r]) +
-                                              (size_t)(a->path_off[r + 1] - a->path_off[r]) * 12 + inputs[b0 + r].name.size() + 160;
+                                              (size_t)(a->path_off[r + 1] - a->path_off[r]) * 8 + inputs[b0 + r].name.size() + 160;
                                    });
         for (uint64_t r = 0; r < n; r++) out.n_aligned += a->aligned[r];
         mark("alignments GAF text");

@@ -274,6 +274,26 @@ def _check_align(oracle, ctx, ix, reads, remain_rule=None):
     return al
 
 
+def test_align_prepare_only_moves_the_allocation(oracle, drb1):
+    """vga_align_prepare (include/vga_hip.h): the traceback memory of the first vga_align_batch call starts to be allocated
+    early, on a thread of its own.  On a context of its own -- first call, then again while the workspace exists, with sizes
+    that are nothing like the reads', and right before the context goes -- the alignments stay the oracle's."""
+    _, ix = drb1
+    c = pkg().Context(0)
+    try:
+        upload_oracle_index(c, ix)
+        reads = pkg().readsim.simulate_reads(DRB1, 10, 2500, 0.03, 0.03, 0.04, seed=23)
+        c.align_prepare(len(reads), 2600)
+        _check_align(oracle, c, ix, reads)
+        c.align_prepare(3, 40)          # (smaller than what exists: nothing to do)
+        c.align_prepare(100000, 60000)  # (far more than the reads need: the call after it still fits)
+        _check_align(oracle, c, ix, reads[:4])
+        c.align_prepare(0, 0)
+        c.align_prepare(5000, 9000)     # (still allocating when the context is destroyed)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("rule", [0, 1], ids=["longest-path", "first-out-edge"])
 def test_remain_rule_of_the_adaptive_band(oracle, ctx, drb1, config4_gfa, monkeypatch, rule):
     """vga_poa_params.remain_rule: which path `remain` (the diagonal term of the adaptive band) follows -- the longest path to
