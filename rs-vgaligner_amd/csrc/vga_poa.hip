@@ -1056,13 +1056,18 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         const size_t nv = (size_t)g.n_ntab - 1;
         const uint32_t nops = ho.nops;
         // one pass over the operations (stored sink -> source), writing through raw pointers into buffers of the largest
-        // possible size: 3 characters per operation for cs ("*ac"), a run of one per operation for the CIGAR ("1M")
-        std::string &cg = it.cigar, &cs = it.cs;
-        cs.resize(5 + 3 * (size_t)nops + 24);
-        cg.resize(2 * (size_t)nops + 24);
-        it.rows.resize(nops);
-        char *c = &cs[0], *d = &cg[0];
-        uint32_t *rowp = it.rows.data();
+        // possible size: 3 characters per operation for cs ("*ac"), a run of one per operation for the CIGAR ("1M").  Those
+        // are scratch of the worker thread; the problem keeps copies of the exact size (the largest possible size is four
+        // times what a 10 kbp read uses: 2.4 GB of touched, unused capacity per 10 000 reads, which the process then carries
+        // to its exit)
+        struct scratch_t { std::vector<char> cs, cg; std::vector<uint32_t> rows; };
+        static thread_local scratch_t sc;
+        if (sc.cs.size() < 5 + 3 * (size_t)nops + 24) sc.cs.resize(5 + 3 * (size_t)nops + 24 + 4096);
+        if (sc.cg.size() < 2 * (size_t)nops + 24) sc.cg.resize(2 * (size_t)nops + 24 + 4096);
+        if (sc.rows.size() < nops) sc.rows.resize((size_t)nops + 1024);
+        char *const cs0 = sc.cs.data(), *const cg0 = sc.cg.data();
+        char *c = cs0, *d = cg0;
+        uint32_t *rowp = sc.rows.data();
         memcpy(c, "cs:Z:", 5);
         c += 5;
         auto put_u = [](char *&w, uint64_t v) {
@@ -1107,9 +1112,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             t2 = u;
         }
         if (eq_run) { *c++ = ':'; put_u(c, eq_run); }
-        cs.resize((size_t)(c - &cs[0]));
-        cg.resize((size_t)(d - &cg[0]));
-        it.rows.resize(n_rows);
+        it.cs.assign(cs0, (size_t)(c - cs0));
+        it.cigar.assign(cg0, (size_t)(d - cg0));
+        it.rows.assign(rowp, rowp + n_rows);
         it.aligned = (uint32_t)aligned;
         // rows ascend along the path: merge-walk the node table to label them
         it.gnodes.resize(it.rows.size());

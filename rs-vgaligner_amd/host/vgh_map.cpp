@@ -30,8 +30,10 @@ void trace_mark(const char *what)
     static const auto t0 = std::chrono::steady_clock::now();
     static auto prev = t0;
     const auto t = std::chrono::steady_clock::now();
-    fprintf(stderr, "[vgh-trace] %-44s +%9.3f ms  (at %9.3f ms)\n", what, std::chrono::duration<double, std::milli>(t - prev).count(),
-            std::chrono::duration<double, std::milli>(t - t0).count());
+    long rss_pages = 0;  // (resident host memory: what the exit of the process will have to give back)
+    if (FILE *f = fopen("/proc/self/statm", "r")) { long sz = 0; if (fscanf(f, "%ld %ld", &sz, &rss_pages) != 2) rss_pages = 0; fclose(f); }
+    fprintf(stderr, "[vgh-trace] %-44s +%9.3f ms  (at %9.3f ms, %5.2f GB resident)\n", what, std::chrono::duration<double, std::milli>(t - prev).count(),
+            std::chrono::duration<double, std::milli>(t - t0).count(), (double)rss_pages * 4096.0 / 1e9);
     prev = t;
 }
 
@@ -345,8 +347,10 @@ void map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &
     auto mark = [&](const char *what) {
         if (!trace) return;
         const auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[vgh-trace] reads [%llu, %llu): %-28s %9.3f ms\n", (unsigned long long)b0, (unsigned long long)e0, what,
-                std::chrono::duration<double, std::milli>(t - t_prev).count());
+        long rss_pages = 0;
+        if (FILE *f = fopen("/proc/self/statm", "r")) { long sz = 0; if (fscanf(f, "%ld %ld", &sz, &rss_pages) != 2) rss_pages = 0; fclose(f); }
+        fprintf(stderr, "[vgh-trace] reads [%llu, %llu): %-28s %9.3f ms  (%5.2f GB resident)\n", (unsigned long long)b0, (unsigned long long)e0, what,
+                std::chrono::duration<double, std::milli>(t - t_prev).count(), (double)rss_pages * 4096.0 / 1e9);
         t_prev = t;
     };
     std::string concat;
