@@ -54,6 +54,31 @@ void vgh_index_free(void *h) { delete (IndexBox *)h; }
 const vga_index_desc *vgh_index_desc(void *h) { return &((IndexBox *)h)->desc; }
 int vgh_index_upload(void *h, vga_ctx *ctx) { return vga_index_upload(ctx, &((IndexBox *)h)->desc); }
 
+// GAFAlignment of one aligned read (src/align.rs:1145-1167) from the fields of a vga_align_result, appended to `prefix`:
+// what the driver's text threads do per read (for CPU tests of the record writer).  Returns malloc'd text (vgh_free).
+char *vgh_gaf_alignment_record(const char *prefix, const char *name, uint64_t seq_len, int aligned, const uint64_t *handles, uint64_t n_handles,
+                               uint32_t path_length, uint32_t path_start, uint32_t path_end, uint32_t block_length, const char *cs, const char *cigar)
+{
+    try {
+        QuerySequence q{name, std::string((size_t)seq_len, 'A')};
+        vga_align_result a;
+        memset(&a, 0, sizeof a);
+        uint8_t al = aligned ? 1 : 0;
+        uint64_t path_off[2] = {0, n_handles}, cs_off[2] = {0, strlen(cs) + 1}, cg_off[2] = {0, strlen(cigar) + 1};
+        a.n_reads = 1;
+        a.aligned = &al;
+        a.path_off = path_off;
+        a.path_handles = const_cast<uint64_t *>(handles);
+        a.path_length = &path_length; a.path_start = &path_start; a.path_end = &path_end; a.block_length = &block_length;
+        a.cs_off = cs_off; a.cs = const_cast<char *>(cs);
+        a.cigar_off = cg_off; a.cigar = const_cast<char *>(cigar);
+        std::string out = prefix;
+        gaf_from_alignment(out, q, &a, 0);
+        if (out != std::string(prefix) + gaf_from_alignment(q, &a, 0)) throw Error("the appending and the returning record writers differ");
+        return dup_str(out);
+    } catch (const std::exception &e) { g_err = e.what(); return nullptr; }
+}
+
 // map_reads over in-memory reads; returns 0 and malloc'd GAF texts (free with vgh_free)
 int vgh_map_reads(vga_ctx *ctx, void *h, uint64_t n, const char *const *names, const char *const *seqs, uint64_t max_gap,
                   uint64_t chain_min_n_anchors, int also_align, uint64_t align_best_n, const char *out_prefix,

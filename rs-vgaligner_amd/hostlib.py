@@ -45,6 +45,9 @@ def load_library():
     L.vgh_map_reads_multi.argtypes = [vp, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64,
                                       C.POINTER(C.c_int), C.c_uint32, C.c_uint64, C.c_char_p, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64)]
+    L.vgh_gaf_alignment_record.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32,
+                                           C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p]
+    L.vgh_gaf_alignment_record.restype = vp
     L.vgh_free.argtypes = [vp]
     _lib = L
     return L
@@ -179,3 +182,18 @@ def read_seqs_from_file(path: str) -> List[Tuple[str, str]]:
         raise HostError(L.vgh_last_error().decode())
     out = [(names[i].decode(), seqs[i].decode()) for i in range(n)]
     return out
+
+
+def gaf_alignment_record(name: str, seq_len: int, aligned: bool, handles: Sequence[int], path_length: int, path_start: int, path_end: int,
+                         block_length: int, cs: str, cigar: str, prefix: str = "") -> str:
+    """the alignments-GAF record the driver's text threads write for one read (vgh::gaf_from_alignment), appended to prefix"""
+    L = load_library()
+    hs = (C.c_uint64 * max(1, len(handles)))(*handles)
+    p = L.vgh_gaf_alignment_record(prefix.encode(), name.encode(), seq_len, 1 if aligned else 0, hs, len(handles), path_length, path_start,
+                                   path_end, block_length, cs.encode(), cigar.encode())
+    if not p:
+        raise HostError(L.vgh_last_error().decode())
+    try:
+        return C.string_at(p).decode()
+    finally:
+        L.vgh_free(p)

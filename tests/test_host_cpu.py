@@ -192,3 +192,30 @@ def test_toposort_gfa_keeps_every_path_sequence_and_orders_the_acyclic_loci(tmp_
             assert st2["flipped"] == 0 and open(again).read() == open(out).read(), name
     assert cyclic == {"5-B3106": (22, 0), "7-MICB-4277": (94, 0), "8-C3107": (31, 0), "10-F-3134": (1, 0), "15-H-3136-spoa": (1, 0),
                       "16-DQB1-3119-spoa": (7, 0), "17-DRB1-3123-smooth": (0, 15), "20-C3107-smooth": (0, 2)}, cyclic
+
+
+def test_alignment_record_writer(oracle):
+    """vgh::gaf_from_alignment (host/vgh_map.cpp) writes GAFAlignment::to_string (src/align.rs:746-760) of generate_alignment's
+    record (src/align.rs:1145-1167) through raw pointers into a buffer sized from an upper bound: the text must be the plain
+    formatting, for short and long ids, either orientation, an empty path, a prefix already in the buffer, and a placeholder."""
+    import random
+    H = pkg().hostlib
+    rng = random.Random(5)
+
+    def expect(name, L, handles, plen, ps, pe, blk, cs, cg):
+        path = "".join(("<" if h & 1 else ">") + str(h >> 1) for h in handles)
+        return "\t".join([name, str(L), "0", str(L), "+", path, str(plen), str(ps), str(pe), "0", str(blk), "255", "as:i:-30 " + cs + ",cg:Z:" + cg]) + "\n"
+
+    cases = [
+        ("r1", 12, [2, 4, 7], 3, 0, 5, 12, "cs:Z::12", "12M"),
+        ("read with spaces", 1, [(2 ** 63 - 1) << 1 | 1], 1, 0, 1, 1, "cs:Z:*ac", "1M"),           # a 19-digit id, reverse
+        ("e", 0, [], 0, 0, 0, 0, "cs:Z:", ""),                                                        # nothing aligned to anything
+        ("big", 10 ** 7, [rng.randrange(1, 10 ** 9) << 1 | rng.randrange(2) for _ in range(5000)], 5000, 3, 9, 10 ** 7,
+         "cs:Z:" + ":7*ag" * 4000, "7M1X" * 4000),
+    ]
+    for prefix in ("", "earlier record\n" * 3):
+        for name, L, hs, plen, ps, pe, blk, cs, cg in cases:
+            got = H.gaf_alignment_record(name, L, True, hs, plen, ps, pe, blk, cs, cg, prefix=prefix)
+            assert got == prefix + expect(name, L, hs, plen, ps, pe, blk, cs, cg)
+    # not aligned: the placeholder of src/align.rs:1012-1028
+    assert H.gaf_alignment_record("nope", 77, False, [], 0, 0, 0, 0, "", "", prefix="x\n") == "x\nnope\t77\t*\t*\t*\t*\t*\t*\t*\t*\t*\t0\t*\n"
