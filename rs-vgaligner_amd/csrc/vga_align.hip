@@ -259,6 +259,8 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     vga_ctx *ctx = b->ctx;
     *out = nullptr;
     if (!ctx->index.loaded) return vga_set_error(ctx, VGA_ERR_NO_INDEX, "vga_align_batch: no index uploaded");
+    (void)hipSetDevice(ctx->device);
+    vga_release_deferred();  // (buffers that grew during an earlier call: freed now, while this context has nothing in flight)
     if (m->n_reads != b->n_reads) return vga_set_error(ctx, VGA_ERR_ARG, "vga_align_batch: chains belong to a different batch");
     const uint64_t R = b->n_reads;
     const uint32_t k = ctx->index.k;

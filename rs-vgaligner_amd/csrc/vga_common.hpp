@@ -107,6 +107,13 @@ int vga_set_error(vga_ctx *ctx, int code, const char *fmt, ...);
                                  hipGetErrorString(e_), __FILE__, __LINE__);                   \
     } while (0)
 
+// hipFree and hipHostFree wait for every kernel that runs on the device.  A buffer that has to grow while launches are in flight
+// (a sub-batch's staging beside a DP launch that runs for a second) would stall the launch path for as long: it hands its old
+// memory to this list instead, which is released by the next call that starts on an idle context (vga_release_deferred: the
+// entry points of map / align / poa) and with the context.
+void vga_defer_release(void *device_ptr, void *pinned_ptr, void *registered_ptr, size_t registered_bytes);
+void vga_release_deferred();
+
 // grow-only device buffer
 template <typename T>
 struct vga_dbuf {
@@ -115,7 +122,7 @@ struct vga_dbuf {
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
+        if (p) vga_defer_release(p, nullptr, nullptr, 0);
         p = nullptr;
         cap = 0;
         size_t want = n + n / 8 + 64;
@@ -152,7 +159,10 @@ struct vga_hbuf {
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
-        release();
+        if (p) vga_defer_release(nullptr, mapped ? nullptr : p, mapped ? p : nullptr, mapped);
+        p = nullptr;
+        cap = 0;
+        mapped = 0;
         const size_t want = n + n / 8 + 64;
         const size_t bytes = (want * sizeof(T) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
         if (bytes >= ((size_t)8 << 20)) {

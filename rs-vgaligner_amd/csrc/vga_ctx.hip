@@ -37,6 +37,38 @@ unsigned vga_host_threads(uint64_t n)
 
 extern "C" int vga_abi_version(void) { return VGA_ABI_VERSION; }
 
+namespace {
+struct deferred_t { void *dev, *pinned, *reg; size_t reg_bytes; int device; };
+std::mutex g_deferred_mu;
+std::vector<deferred_t> g_deferred;
+}  // namespace
+
+void vga_defer_release(void *device_ptr, void *pinned_ptr, void *registered_ptr, size_t registered_bytes)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_deferred_mu);
+    g_deferred.push_back({device_ptr, pinned_ptr, registered_ptr, registered_bytes, dev});
+}
+
+void vga_release_deferred()
+{
+    std::vector<deferred_t> todo;
+    {
+        std::lock_guard<std::mutex> lk(g_deferred_mu);
+        todo.swap(g_deferred);
+    }
+    if (todo.empty()) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const deferred_t &d : todo) {
+        if (d.dev) { (void)hipSetDevice(d.device); (void)hipFree(d.dev); }
+        if (d.pinned) (void)hipHostFree(d.pinned);
+        if (d.reg) { (void)hipHostUnregister(d.reg); (void)munmap(d.reg, d.reg_bytes); }
+    }
+    (void)hipSetDevice(cur);
+}
+
 extern "C" const char *vga_last_error(const vga_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
 extern "C" int vga_ctx_create(int device, vga_ctx **out)
@@ -103,6 +135,7 @@ extern "C" void vga_ctx_destroy(vga_ctx *ctx)
     vga_index_release(ctx->index);
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    vga_release_deferred();
     delete ctx;
 }
 

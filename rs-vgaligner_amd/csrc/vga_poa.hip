@@ -1365,6 +1365,8 @@ static int vga_poa_batch_impl(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr
     if (!ctx || !out || !params || (n && (!node_ptr || !node_off || !nodes_concat || !edge_ptr || !query_off || !queries_concat)))
         return VGA_ERR_ARG;
     *out = nullptr;
+    (void)hipSetDevice(ctx->device);
+    vga_release_deferred();  // (buffers that grew during an earlier call: freed now, while this context has nothing in flight)
     poa_feed feed;
     std::vector<poa_view> &views = feed.views;
     views.resize(n);
