@@ -10,15 +10,16 @@ REPO=$GRAFT_REPO_ROOT
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# the counter passes look at the timed step only (bench.py otherwise adds two steps under the other remain rule)
 timeout -k 10 500 python3 $REPO/bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"; tail -c 600 $OUT/bench.json
 timeout -k 10 500 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 $REPO/bench.py --cpu-sample 0 > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 echo "kernel trace done"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_poa_dp" -d $OUT/pmc_$c -o pmc --output-format csv -- python3 $REPO/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
+  VGA_BENCH_NO_OTHER_RULE=1 timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_poa_dp" -d $OUT/pmc_$c -o pmc --output-format csv -- python3 $REPO/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/bench_pmc_$c.json 2> $OUT/pmc_$c.err
   echo "pmc $c done"
 done
 # instruction counters of the same step (the issue-rate fraction in bench.py's roofline.valu comes from these)
-timeout -k 10 500 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_BANK_CONFLICT --kernel-trace --kernel-include-regex "k_poa_dp" -d $OUT/pmc_INSTS -o pmc --output-format csv -- python3 $REPO/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/bench_pmc_INSTS.json 2> $OUT/pmc_INSTS.err
+VGA_BENCH_NO_OTHER_RULE=1 timeout -k 10 500 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_BANK_CONFLICT --kernel-trace --kernel-include-regex "k_poa_dp" -d $OUT/pmc_INSTS -o pmc --output-format csv -- python3 $REPO/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/bench_pmc_INSTS.json 2> $OUT/pmc_INSTS.err
 echo "pmc INSTS done"
 find $OUT -name "*.csv" | head -20

@@ -18,7 +18,7 @@ for spec in "$@"; do
     lbl=$(echo "$spec" | tr ':,=' '___')
     timeout -k 10 300 python3 $REPO/bench.py $BENCH_ARGS --reads $READS --steps $STEPS --warmup 1 --cpu-sample 0 > $OUT/bench_$lbl.json 2> $OUT/bench_$lbl.err || { echo "$spec: bench failed"; tail -3 $OUT/bench_$lbl.err; exit 1; }
     if [ "${PMC:-1}" = "1" ]; then
-      timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --kernel-include-regex "k_poa_dp" -d $OUT/pmc_$lbl -o pmc --output-format csv -- python3 $REPO/bench.py $BENCH_ARGS --reads ${PMC_READS:-2000} --steps 1 --warmup 0 --cpu-sample 0 > $OUT/pmcbench_$lbl.json 2> $OUT/pmc_$lbl.err || { echo "$spec: pmc failed"; tail -3 $OUT/pmc_$lbl.err; }
+      VGA_BENCH_NO_OTHER_RULE=1 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace --kernel-include-regex "k_poa_dp" -d $OUT/pmc_$lbl -o pmc --output-format csv -- python3 $REPO/bench.py $BENCH_ARGS --reads ${PMC_READS:-2000} --steps 1 --warmup 0 --cpu-sample 0 > $OUT/pmcbench_$lbl.json 2> $OUT/pmc_$lbl.err || { echo "$spec: pmc failed"; tail -3 $OUT/pmc_$lbl.err; }
     fi
     python3 - "$spec" $OUT/bench_$lbl.json $OUT/pmcbench_$lbl.json $OUT/pmc_$lbl <<'PY'
 import csv, glob, json, sys, collections

@@ -14,9 +14,22 @@ shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"), os.path.join(dst, f"
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{rnd}_{tag}_bench_10k.json"))
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, f"{rnd}_{tag}_bench_10k_under_rocprof.json"))
 last = lambda f: json.loads(open(os.path.join(src, f)).read().strip().splitlines()[-1])
+
+
+def step_rows(path, launches):
+    """the counter rows of the timed step: its `launches` dispatches come first; what follows them in the same process (bench.py's
+    look at the other remain rule, unless VGA_BENCH_NO_OTHER_RULE=1 was set) is not part of the step"""
+    rows = list(csv.DictReader(open(path)))
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    keep = set(ids[:launches])
+    return [r for r in rows if int(r["Dispatch_Id"]) in keep], len(ids)
+
+
 out, vals, launches, alg = [], {}, 0, 0
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    rows = list(csv.DictReader(open(os.path.join(src, f"pmc_{c}", "pmc_counter_collection.csv"))))
+    b = last(f"bench_pmc_{c}.json")
+    rows, n_disp = step_rows(os.path.join(src, f"pmc_{c}", "pmc_counter_collection.csv"), b["roofline"]["launches"])
+    out.append(f"# the {b['roofline']['launches']} dispatches of the timed step (of {n_disp} in the process)")
     out.append(f"# rocprofv3 --pmc {c} --kernel-trace --kernel-include-regex k_poa_dp -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0")
     out.append("dispatch,kernel,grid,workgroup,counter,value")
     tot = 0.0
@@ -50,7 +63,10 @@ if os.path.exists(ip):
     tot, kname = collections.Counter(), ""
     lines = ["# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_LDS_BANK_CONFLICT "
              "--kernel-trace --kernel-include-regex k_poa_dp -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0", "dispatch,kernel,counter,value"]
-    for r in csv.DictReader(open(ip)):
+    bi = last("bench_pmc_INSTS.json")
+    irows, n_disp = step_rows(ip, bi["roofline"]["launches"])
+    lines.insert(0, f"# the {bi['roofline']['launches']} dispatches of the timed step (of {n_disp} in the process)")
+    for r in irows:
         tot[r["Counter_Name"]] += float(r["Counter_Value"])
         kname = r["Kernel_Name"].split("(")[0]
         lines.append(",".join([r["Dispatch_Id"], r["Kernel_Name"][:32].replace(",", ";"), r["Counter_Name"], r["Counter_Value"]]))
