@@ -82,7 +82,16 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
     unsigned long long *pool_next_arg = A.pool_next;
     const uint64_t pool_size_arg = A.pool_size;
     const uint32_t lds_cols = t5_own(A.lds_cols), hg_cols = t5_own(A.hg_cols), win_mask = t5_own(A.win_mask);
-    const bool chunked = A.cp.n_slots != 0;
+    // Conditions that hold for the whole problem or are carried from row to row live as bits of ONE scalar register, laundered at
+    // the top of every row: as `bool`s the compiler keeps each of them as a 64-bit lane mask (two scalar registers, or two
+    // spill lanes and two v_readlane per use) for as long as it lives
+    enum : uint32_t { ST_CHUNKED = 1u, ST_QPLAIN = 2u, ST_FAILED = 4u, ST_PREV_LDS = 8u, ST_PREV_FAR_USE = 16u };
+    uint32_t st = (A.cp.n_slots != 0 ? ST_CHUNKED : 0u) | ST_PREV_LDS;
+#define chunked ((st & ST_CHUNKED) != 0)
+#define failed ((st & ST_FAILED) != 0)
+#define q_plain ((st & ST_QPLAIN) != 0)
+#define prev_lds ((st & ST_PREV_LDS) != 0)
+#define prev_far_use ((st & ST_PREV_FAR_USE) != 0)
     struct { int match, mismatch, o1, e1, o2, e2, banded; } P = {t5_own(A.P.match), t5_own(A.P.mismatch), A.P.o1, A.P.e1, A.P.o2, A.P.e2, t5_own(A.P.banded)};
     constexpr int NW = NT / 64;
     constexpr int STEP = NT * 4;
@@ -160,11 +169,13 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
     // larger than a chunk takes whole chunks of its own.  A new chunk is taken by one lane and handed round through LDS:
     // every wave reaches this branch in the same row (the condition only depends on replicated state), `slot` keeps the
     // two requests of one row apart.
-    bool failed = false;
     uint32_t own_head = POA_NIL, own_tail = POA_NIL, own_chunks = 0;  // chunk pool: the chunks this workgroup holds (a list through cp.next)
-    auto alloc = [&](uint64_t &cur, uint64_t &end, uint64_t bytes, int slot) -> uint64_t {
-        bytes = (bytes + 15ull) & ~15ull;
-        if (__builtin_expect(cur + bytes > end, 0)) {
+    // (`rem`: the bytes left of the piece `cur` points into -- a 32-bit count, so that the test of every row is one scalar compare;
+    // a 64-bit "cur + bytes > end" goes through the vector ALU.  No request reaches 4 GiB: a row has at most 2^24 + 8 columns of
+    // at most 6 bytes, the ring at most POA_RING_SPAN + 1 = 33 such rows, 3.3 GB.)
+    auto alloc = [&](uint64_t &cur, uint32_t &rem, uint32_t bytes_asked, int slot) -> uint64_t {
+        const uint32_t bytes = (bytes_asked + 15u) & ~15u;
+        if (__builtin_expect(bytes > rem, 0)) {
             if (chunked) {
                 if (slot == 0 && bytes <= POA_CHUNK) {
                     // direction rows: the next chunk from the free list, chained in front of the ones this workgroup holds
@@ -176,30 +187,31 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
                     __syncthreads();
                     const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sChunk[0]);
                     __syncthreads();
-                    if (idx == POA_NIL) failed = true;
+                    if (idx == POA_NIL) st |= ST_FAILED;
                     else {
                         own_head = idx;
                         if (own_tail == POA_NIL) own_tail = idx;
                         own_chunks++;
                         cur = poa_uniform_u64(poa_chunk_addr(A.cp, idx));
-                        end = cur + POA_CHUNK;
+                        rem = (uint32_t)POA_CHUNK;
                     }
                 } else
-                    failed = true;  // (the state region is exhausted, or a row larger than a chunk: the classic pass takes the problem)
+                    st |= ST_FAILED;  // (the state region is exhausted, or a row larger than a chunk: the classic pass takes the problem)
                 if (failed) return cur;
             } else {
-                const uint64_t need = bytes > POA_CHUNK ? (bytes + POA_CHUNK - 1) & ~(POA_CHUNK - 1) : POA_CHUNK;
+                const uint64_t need = bytes > POA_CHUNK ? ((uint64_t)bytes + POA_CHUNK - 1) & ~(POA_CHUNK - 1) : POA_CHUNK;
                 if (tid == 0) sChunk[slot] = atomicAdd(pool_next, (unsigned long long)need);
                 __syncthreads();
                 const uint64_t b = t5_uniform64(sChunk[slot]);
                 __syncthreads();  // (rare path: the slot may be written again as soon as every wave has read it)
-                if (b + need > pool_size) failed = true;
+                if (b + need > pool_size) st |= ST_FAILED;
                 cur = b;
-                end = b + need;
+                rem = (uint32_t)need;
             }
         }
         const uint64_t r = cur;
         cur += bytes;
+        rem -= bytes;
         return r;
     };
 
@@ -221,36 +233,36 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
         }
         Qn[t] = (uint16_t)hw;
     }
-    const bool q_plain = __builtin_amdgcn_readfirstlane(__syncthreads_or(non_acgt)) == 0;
+    if (__builtin_amdgcn_readfirstlane(__syncthreads_or(non_acgt)) == 0) st |= ST_QPLAIN;
 
-    uint64_t dcur = 0, dend = 0, vcur = state_lo, vendp = state_hi, wide_scratch = 0, ring_base = 0;
+    uint64_t dcur = 0, vcur = state_lo, wide_scratch = 0, ring_base = 0;
+    uint32_t dend = 0, vendp = (uint32_t)(state_hi - state_lo);  // (bytes left, see alloc)
     uint32_t ring_head = 0;  // the slot the next node-end row takes
     uint32_t ring_size;      // bytes per slot of the ring: one worst-case row
-    if (win_mask != 0xFFFFFFFFu) wide_scratch = alloc(vcur, vendp, 2ull * 6ull * lds_cols, 1);
+    if (win_mask != 0xFFFFFFFFu) wide_scratch = alloc(vcur, vendp, 2u * 6u * lds_cols, 1);
     {
         const uint64_t maxrow = (6ull * (uint64_t)((qlen + 8) & ~3) + 15ull) & ~15ull;
         ring_size = (uint32_t)maxrow;
         if (chunked) {
-            ring_base = alloc(vcur, vendp, maxrow * (uint64_t)ring_rows, 1);  // (out of the state region)
+            ring_base = alloc(vcur, vendp, (uint32_t)(maxrow * (uint64_t)ring_rows), 1);  // (out of the state region)
         } else {
             const uint64_t rb = (maxrow * (uint64_t)ring_rows + POA_CHUNK - 1) & ~(POA_CHUNK - 1);
             if (tid == 0) sChunk[2] = atomicAdd(pool_next, (unsigned long long)rb);
             __syncthreads();
             const uint64_t b = t5_uniform64(sChunk[2]);
-            if (b + rb > pool_size || rb >= (1ull << 32)) failed = true;
+            if (b + rb > pool_size || rb >= (1ull << 32)) st |= ST_FAILED;
             ring_base = b;
         }
     }
     if (tid == 0) { sSink[2] = POA_NEG; sSink[3] = 0; }  // best sink value so far / its row + 1 (0: none yet)
     int prev_beg = 0, prev_end = -1;
-    bool prev_lds = true, prev_far_use = false;
     uint32_t seq_word = 0, seq_word_idx = 0xFFFFFFFFu;
-    bool stop = false;
 
-    for (uint32_t v = 0; v < n_nodes && !stop; v++) {
+    for (uint32_t v = 0; v < n_nodes && !failed; v++) {
     const uint4 nt = ntab[v];
     const uint32_t nlen = nt.y & 0xFFFFFFu;
-    for (uint32_t tn = 0; tn < nlen && !stop; tn++) {
+    for (uint32_t tn = 0; tn < nlen && !failed; tn++) {
+        asm volatile("" : "+s"(st));
         POA_MARK("row_topo");
         const uint32_t r = nt.x + tn;
         const bool last = tn + 1 == nlen;
@@ -377,12 +389,12 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
         const int W = (end - bal + 1 + 3) & ~3;
         const bool wide = (uint32_t)W + 8u > hg_cols;
         const bool keep = last || wide;
-        const uint64_t doff = alloc(dcur, dend, (uint64_t)W * (np > 1 ? 4u : 1u), 0);
+        const uint64_t doff = alloc(dcur, dend, (uint32_t)W * (np > 1 ? 4u : 1u), 0);
         uint64_t voff = 0;
         if (last && !failed) {
             // (a value row that outlives the ring: chunk-pool mode keeps it among the direction rows, whose chunks stay with the
             // workgroup to the end; the state region only holds the ring and the scratch rows)
-            if (r == 0 || (nt.z & 0x40000000u)) voff = chunked ? alloc(dcur, dend, 6ull * (uint64_t)W, 0) : alloc(vcur, vendp, 6ull * (uint64_t)W, 1);
+            if (r == 0 || (nt.z & 0x40000000u)) voff = chunked ? alloc(dcur, dend, 6u * (uint32_t)W, 0) : alloc(vcur, vendp, 6u * (uint32_t)W, 1);
             else {
                 // fixed slots of one worst-case row: the rows of the last ring_rows node ends survive whatever their
                 // widths (a byte ring that wraps when a row does not fit can overwrite the row written two slots ago)
@@ -390,7 +402,7 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
                 ring_head = ring_head + 1 == ring_rows ? 0 : ring_head + 1;
             }
         } else if (wide) voff = wide_scratch + (r & 1u) * 6ull * lds_cols;
-        if (__builtin_expect(failed, 0)) { stop = true; break; }
+        if (__builtin_expect(failed, 0)) break;
         if (writer && lane == 0) {
             R[r].beg = beg; R[r].end = end;
             R[r].doff = doff; R[r].voff = voff;
@@ -1006,8 +1018,7 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
             if (sSink[3] == 0 || val > sSink[2]) { sSink[2] = val; sSink[3] = (int)r + 1; }
         }
         prev_beg = beg; prev_end = end;
-        prev_lds = !wide;
-        prev_far_use = last;  // (row 0 is the last row of the source entry)
+        st = (st & ~(ST_PREV_LDS | ST_PREV_FAR_USE)) | (wide ? 0u : ST_PREV_LDS) | (last ? ST_PREV_FAR_USE : 0u);  // (row 0 is the last row of the source entry)
     }
     }
     __syncthreads();
@@ -1067,3 +1078,8 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
         }
     }
 }
+#undef chunked
+#undef failed
+#undef q_plain
+#undef prev_lds
+#undef prev_far_use
