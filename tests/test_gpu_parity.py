@@ -519,6 +519,23 @@ def test_poa_paths_the_library_can_fall_back_to(oracle, ctx, drb1, monkeypatch, 
     _check_align(oracle, ctx, ix, pkg().readsim.simulate_reads(DRB1, n, 2500, 0.03, 0.03, 0.04, seed=12))
 
 
+def test_chunk_pool_that_starts_far_too_small(oracle, drb1, monkeypatch):
+    """The traceback pool of chunk-pool mode under shortage: it starts at a fraction of what the resident problems write
+    (VGA_POOL_FILL) and can only grow in small segments (VGA_POOL_SEG; at most 80 of them), so workgroups find the free lists
+    empty, raise the shortage flag, wait for the keeper thread to list new segments, and some give their problem up -- to a second
+    chunk-mode pass and then to the classic pass.  Whatever route a problem took, its alignment is the oracle's."""
+    monkeypatch.setenv("VGA_POOL_FILL", "0.002")
+    monkeypatch.setenv("VGA_POOL_SEG", str(32 << 20))
+    _, ix = drb1
+    c = pkg().Context(0)
+    try:
+        upload_oracle_index(c, ix)
+        reads = pkg().readsim.simulate_reads(DRB1, 320, 2500, 0.03, 0.03, 0.04, seed=41)
+        _check_align(oracle, c, ix, reads)
+    finally:
+        c.close()
+
+
 def test_batch_outlives_its_context(drb1, oracle):
     """a vga_batch handle destroyed after vga_ctx_destroy (the order a garbage collector picks) must not touch the
     freed context, and must not disturb the next context of the process"""
