@@ -270,10 +270,14 @@ std::vector<Shard> plan_shards(const std::vector<uint64_t> &len, uint32_t n_slot
             const double target = (double)(total * (uint64_t)(slot + 1)) / (double)n_slots;
             while (end < n && (double)acc + (double)len[end] / 2.0 <= target) { acc += len[end]; end++; }
         }
-        for (uint64_t c = start; c < end;) {
-            const uint64_t e = chunk_reads ? std::min<uint64_t>(end, c + chunk_reads) : end;
-            out.push_back({c, e, slot});
-            c = e;
+        // chunks of equal size, as few as chunk_reads allows: a slice of 100 000 reads in chunks of at most 32 768 is four chunks of
+        // 25 000, not three full ones and a rest of 1 696 -- every chunk ends with the tail of its longest alignments, a cost the
+        // rest would pay for almost nothing
+        const uint64_t len_slice = end - start;
+        const uint64_t n_chunks = chunk_reads ? (len_slice + chunk_reads - 1) / chunk_reads : (len_slice ? 1 : 0);
+        for (uint64_t q = 0; q < n_chunks; q++) {
+            const uint64_t c = start + len_slice * q / n_chunks, e = start + len_slice * (q + 1) / n_chunks;
+            if (e > c) out.push_back({c, e, slot});
         }
         start = end;
     }
