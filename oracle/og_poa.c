@@ -192,6 +192,9 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
     size_t *preds = (size_t *)malloc(pbuf_cap * sizeof(size_t));
     uint64_t n_cells_rows = 0;
 
+    /* diagnostics (OG_POA_WIDTHS=<file>): band-width statistics of every problem, appended as one line */
+    const char *width_stat = getenv("OG_POA_WIDTHS");
+    size_t ws_max = 0, ws_sum = 0, ws_over512 = 0, ws_over1024 = 0;
     for (size_t r = 0; r <= N; r++) {
         int64_t diag = qlen - remain[r];
         int64_t b, e;
@@ -204,6 +207,7 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
         }
         beg[r] = b; end[r] = e; off[r] = cells;
         size_t width = (size_t)(e - b + 1);
+        if (width_stat) { if (width > ws_max) ws_max = width; ws_sum += width; if ((size_t)(e - (b & ~7)) + 1 > 512) ws_over512++; if ((size_t)(e - (b & ~7)) + 1 > 1024) ws_over1024++; }
         if (cells + width > ccap) {
             size_t nc = ccap ? ccap : (1u << 20);
             while (nc < cells + width) nc *= 2;
@@ -460,6 +464,10 @@ int og_poa_align(const char *const *nodes, const size_t *node_lens, size_t n_nod
 cleanup:
     free(first_row); free(last_row); free(row_base); free(row_node);
     free(in_off); free(out_off); free(in_adj); free(out_adj);
+    if (width_stat) {
+        FILE *wf = fopen(width_stat, "a");
+        if (wf) { fprintf(wf, "rows %zu qlen %lld max %zu mean %.1f over512 %zu over1024 %zu\n", N, (long long)qlen, ws_max, (double)ws_sum / (double)(N + 1), ws_over512, ws_over1024); fclose(wf); }
+    }
     free(remain); free(mpl); free(mpr); free(beg); free(end); free(off);
     free(H); free(HT); free(E1); free(E2); free(F1); free(F2); free(preds);
     return OG_OK;

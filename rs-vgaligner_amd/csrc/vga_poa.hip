@@ -38,6 +38,7 @@
 #include "vga_poa_kernels.hpp"
 #include "vga_poa_t4.hpp"
 #include "vga_poa_t5.hpp"
+#include "vga_poa_t6.hpp"
 
 // One workgroup per staged problem: copies its node table, predecessor rows, sink rows, bases and query from the device
 // store of vga_subgraph.hip (and the batch's reads) to where this sub-batch's poa_prob says they are.
@@ -907,6 +908,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                     want = w2;
                 }
                 if (giant) want = 8192;
+                if (giant && getenv("VGA_POA_GIANT_WINDOW")) want = (uint32_t)strtoul(getenv("VGA_POA_GIANT_WINDOW"), nullptr, 10);  // (0: every column)
                 const char *ew = getenv("VGA_POA_WINDOW");
                 if (ew) want = (uint32_t)strtoul(ew, nullptr, 10);
                 set_window(want);
@@ -968,7 +970,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 poa_chunk_pool cp_arg = CP;
                 if (!arena) cp_arg.n_slots = 0;
                 const poa_t5_args t5a = {S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, S.d_rows.p, pool_base, W.d_next.p + slot, half_pool,
-                                         S.d_outs.p, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr), cp_arg, lds_cols, hg_cols, win_mask, P};
+                                         S.d_outs.p, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr), cp_arg, lds_cols, hg_cols, win_mask, P,
+                                         (giant && !(getenv("VGA_POA_GIANT_PRIO") && atoi(getenv("VGA_POA_GIANT_PRIO")) == 0)) ? 1u : 0u};
                 (void)t5a;
 #define POA_T4_ARGS S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, P, S.d_rows.p, pool_base, W.d_next.p + slot, half_pool,   \
                     S.d_outs.p, lds_cols, hg_cols, win_mask, (sub_fused ? S.d_ops.p : nullptr), (sub_fused ? S.d_orow.p : nullptr),       \
@@ -989,6 +992,21 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             hipLaunchKernelGGL((k_poa_dp_t4<T, false>), dim3(nb), dim3(T), lds, st, POA_T4_ARGS);                           \
         }                                                                                                                    \
         break;
+                // k_poa_dp_t6 (vga_poa_t6.hpp): one wave per problem, the row in registers -- launches of narrow bands in chunk-pool
+                // mode with the fused traceback; what does not fit its window comes back with POA_ST_RETRY and runs below
+                const bool t6_forced = force && strstr(force, "t6");
+                const bool t6 = t5 && arena && sub_fused && !general && !giant && !(force && strstr(force, "t5")) && (t6_forced || mean_w <= 800.0);
+                if (t6) {
+                    const size_t lds6 = poa_t6_lds_bytes<8>(lds_cols);
+                    if (tr.on) fprintf(stderr, "[vga-trace] poa:     k_poa_dp_t6<8>: one wave per problem, LDS %zu B\n", lds6);
+                    if (def_pen) {
+                        chk(hipFuncSetAttribute((const void *)k_poa_dp_t6<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6));
+                        hipLaunchKernelGGL((k_poa_dp_t6<8, true>), dim3(nb), dim3(64), lds6, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t5a);
+                    } else {
+                        chk(hipFuncSetAttribute((const void *)k_poa_dp_t6<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6));
+                        hipLaunchKernelGGL((k_poa_dp_t6<8, false>), dim3(nb), dim3(64), lds6, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t5a);
+                    }
+                } else
                 switch (nt) {
                     POA_T4_LAUNCH(128) POA_T4_LAUNCH(192) POA_T4_LAUNCH(256) POA_T4_LAUNCH(320)
                     POA_T4_LAUNCH(384) POA_T4_LAUNCH(448) POA_T4_LAUNCH(512) POA_T4_LAUNCH(768) POA_T4_LAUNCH(1024)

@@ -56,6 +56,8 @@ struct poa_t5_args {
     poa_chunk_pool cp;  // cp.n_slots != 0: direction rows out of the chunk pool, the rest out of a state region
     uint32_t lds_cols, hg_cols, win_mask;
     poa_dev_params P;
+    uint32_t prio;  // != 0: the waves of this launch run at raised issue priority (the launch of a call's longest problems: their
+                    // sequential rows decide how long the call takes, so they should not share issue slots evenly with the bulk)
 };
 // a scalar of its own: cuts a uniform value loose from the (wide) load that produced it
 __device__ __forceinline__ int t5_own(int v)
@@ -108,6 +110,7 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
     const int edge_idx = (int)(edgeW - Hs);
 
     if (threadIdx.x == 0) A.outs[blockIdx.x].t_begin = __builtin_amdgcn_s_memrealtime();
+    if (A.prio) __builtin_amdgcn_s_setprio(3);
     const poa_prob pb = probs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qlen = t5_own((int)pb.qlen);

@@ -500,13 +500,15 @@ def _fallback_problems(rng):
                                  {"VGA_POA_KERNEL": "t4"}, {"VGA_POA_KERNEL": "t4", "VGA_POA_ARENAS": "0"}, {"VGA_POA_KERNEL": "generic"},
                                  {"VGA_POA_TB": "wave"}, {"VGA_POOL_BYTES": "300000000"}, {"VGA_POA_SUB": "7"}, {"VGA_POA_WINDOW": "256"},
                                  {"VGA_POA_NT": "512"}, {"VGA_POA_NT": "1024"}, {"VGA_POA_NT": "512", "VGA_POA_ARENAS": "0"},
-                                 {"VGA_SG_SPLIT": "1"}, {"VGA_SG_SPLIT": "2", "VGA_POA_SUB": "2", "VGA_POOL_BYTES": "300000000", "VGA_POA_ARENAS": "0"}],
+                                 {"VGA_SG_SPLIT": "1"}, {"VGA_SG_SPLIT": "2", "VGA_POA_SUB": "2", "VGA_POOL_BYTES": "300000000", "VGA_POA_ARENAS": "0"},
+                                 {"VGA_POA_KERNEL": "t6"}, {"VGA_POA_KERNEL": "t6,generic"}, {"VGA_POA_KERNEL": "t5"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_poa_paths_the_library_can_fall_back_to(oracle, ctx, drb1, monkeypatch, env):
     """the configurations poa_run selects by itself when it has to -- classic pool instead of arenas (problems too large for
     an arena), k_poa_dp_lds (gap penalties beyond the byte range of k_poa_dp_t4), a traceback kernel of its own, a pool so
     small that sub-batches are re-queued, tiny sub-batches, a narrow LDS window (HBM detour of wide rows), the workgroup sizes of large launches (512) and of
-    very long problems (1 024), the subgraph store
+    very long problems (1 024), the one-wave-per-problem kernel of narrow bands on every launch (k_poa_dp_t6: what does not fit its
+    window comes back and runs in k_poa_dp_t5) and switched off, the subgraph store
     in two parts (the second prepared beside the first launch) with launches and re-runs that draw on both -- forced
     through their environment switches and held to the same parity"""
     for k, v in env.items():
