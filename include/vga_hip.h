@@ -41,7 +41,19 @@ typedef struct vga_ctx vga_ctx;
  * when no GPU is present. */
 int vga_ctx_create(int device, vga_ctx **out);
 void vga_ctx_destroy(vga_ctx *ctx);
+/* Message of the last error of `ctx`.  The pointer is a copy that belongs to the calling thread (valid until that thread calls
+ * vga_last_error again); two entry points of one context may run on two threads (vga_chain_paths_text beside vga_align_batch)
+ * and each may read it. */
 const char *vga_last_error(const vga_ctx *ctx);
+/* Per-context settings (replace the VGA_POOL_FRACTION / VGA_HOST_THREADS environment hand-off of ABI <= 5; src/map.rs has no
+ * counterpart: the reference is single-threaded and holds no device memory).
+ *   vga_ctx_set_pool_fraction: the share (0, 1] of the device memory that is free when vga_align_batch sizes its traceback pool
+ *     that THIS context may take -- 1 / n for n contexts on one GPU (`vgaligner map --devices 0,0`).  Default 1.
+ *   vga_ctx_set_host_threads: host threads the calls of this context fan out to (subgraph fallback, CIGAR / cs strings, result
+ *     copies); 0 = the default (VGA_HOST_THREADS if set, else the hardware's concurrency, at most 32).
+ * Both take effect with the next call on the context; VGA_ERR_ARG outside those ranges. */
+int vga_ctx_set_pool_fraction(vga_ctx *ctx, double fraction);
+int vga_ctx_set_host_threads(vga_ctx *ctx, uint32_t n_threads);
 /* Blocks until all work queued on the ctx's stream has finished. */
 int vga_ctx_synchronize(vga_ctx *ctx);
 /* ABI version of the library (bumped on any signature change). */
@@ -234,6 +246,7 @@ typedef struct {
     char *cs;
     uint64_t poa_rows, poa_cells, poa_value_cells, poa_problems; /* totals for the byte model */
     float ms_subgraph, ms_dp, ms_traceback, ms_total;
+    uint64_t result_bytes;       /* what crossed PCIe for cs / CIGAR / node paths: their text (K4c) or the raw traceback operations (ABI 6) */
 } vga_align_result;
 
 int vga_align_batch(vga_batch *b, const vga_map_result *chains, uint32_t align_best_n,

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "vga_index_upload", "vga_batch_create", "vga_batch_destroy", "vga_map_default_params", "vga_map_batch",
     "vga_map_result_free", "vga_poa_default_params", "vga_poa_result_free", "vga_poa_batch", "vga_align_batch",
     "vga_align_result_free", "vga_last_kernel_times", "vga_chain_paths_text", "vga_chain_text_free",
-    "vga_align_prepare",
+    "vga_align_prepare", "vga_ctx_set_pool_fraction", "vga_ctx_set_host_threads",
 ]
 
 
@@ -100,6 +100,7 @@ class AlignResult(C.Structure):
         ("cigar", _P(C.c_char)), ("cs_off", _P(C.c_uint64)), ("cs", _P(C.c_char)),
         ("poa_rows", C.c_uint64), ("poa_cells", C.c_uint64), ("poa_value_cells", C.c_uint64), ("poa_problems", C.c_uint64),
         ("ms_subgraph", C.c_float), ("ms_dp", C.c_float), ("ms_traceback", C.c_float), ("ms_total", C.c_float),
+        ("result_bytes", C.c_uint64),
     ]
 
 
@@ -143,6 +144,10 @@ def load_library():
     L.vga_chain_paths_text.argtypes = [vp, _P(MapResult), _P(_P(ChainText))]
     L.vga_align_prepare.argtypes = [vp, C.c_uint64, C.c_uint32]
     L.vga_align_prepare.restype = C.c_int
+    L.vga_ctx_set_pool_fraction.argtypes = [vp, C.c_double]
+    L.vga_ctx_set_pool_fraction.restype = C.c_int
+    L.vga_ctx_set_host_threads.argtypes = [vp, C.c_uint32]
+    L.vga_ctx_set_host_threads.restype = C.c_int
     L.vga_chain_text_free.argtypes = [_P(ChainText)]
     _lib = L
     return L
@@ -346,7 +351,7 @@ class Batch:
             out = dict(n_reads=R, aligned=aligned, n_anchors=int(q.n_anchors), n_hits=int(q.n_hits),
                        poa_rows=int(r.poa_rows), poa_cells=int(r.poa_cells), poa_value_cells=int(r.poa_value_cells),
                        poa_problems=int(r.poa_problems), path_bases=int(np.ctypeslib.as_array(r.path_length, shape=(R,)).sum()) if R else 0,
-                       cigar_bytes=int(r.cigar_off[R]) if R else 0,
+                       cigar_bytes=int(r.cigar_off[R]) if R else 0, result_bytes=int(r.result_bytes),
                        ms_map=float(q.ms_total), ms_probe=float(q.ms_probe), ms_sort=float(q.ms_sort), ms_chain=float(q.ms_chain),
                        ms_align=float(r.ms_total), ms_subgraph=float(r.ms_subgraph), ms_dp_summed_launches=float(r.ms_dp),
                        ms_traceback=float(r.ms_traceback), kernels=kt_map + kt_aln)
@@ -387,6 +392,14 @@ class Context:
     def _check(self, rc: int):
         if rc != VGA_OK:
             raise VgaError(rc, self.L.vga_last_error(self.h).decode())
+
+    def set_pool_fraction(self, fraction: float):
+        """share of the device's free memory this context's traceback pool may take (contexts that share a GPU)"""
+        self._check(self.L.vga_ctx_set_pool_fraction(self.h, float(fraction)))
+
+    def set_host_threads(self, n: int):
+        """host threads this context's calls fan out to (0: the default)"""
+        self._check(self.L.vga_ctx_set_host_threads(self.h, int(n)))
 
     def upload_index(self, k: int, seq_fwd: bytes, node_seq_idx, node_edge_idx, node_edges_to, edges, kmer_keys: bytes,
                      kmer_starts, kmer_pos_table: np.ndarray):

@@ -260,7 +260,8 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     *out = nullptr;
     if (!ctx->index.loaded) return vga_set_error(ctx, VGA_ERR_NO_INDEX, "vga_align_batch: no index uploaded");
     (void)hipSetDevice(ctx->device);
-    vga_release_deferred();  // (buffers that grew during an earlier call: freed now, while this context has nothing in flight)
+    vga_ctx_scope scope(ctx);
+    vga_release_deferred(ctx);  // (buffers of this context that grew during an earlier call: freed now, while it has nothing in flight)
     if (m->n_reads != b->n_reads) return vga_set_error(ctx, VGA_ERR_ARG, "vga_align_batch: chains belong to a different batch");
     const uint64_t R = b->n_reads;
     const uint32_t k = ctx->index.k;
@@ -364,6 +365,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         if (rc != VGA_OK) return rc;
         sub_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
         feed.dev = &store;
+        feed.want_rows = false;  // (this caller reads the deduplicated path, its length and the strings: k_poa_text may write them)
         // The rows of the first part's problems are known now.  Very long ones (config 3's longest have 21 000 rows; a chain
         // that spans 100 kbp of the linearisation has 110 000, all sequential) decide how long the call takes: they go
         // first, in a launch of their own with 512 threads and an 8 192-column window (poa_run).  The order inside the
@@ -439,7 +441,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         for (uint64_t q = read_prob0[r]; q < read_prob0[r + 1]; q++) {
             const uint64_t p = slot_of[q];
             if (!items[p].ok) continue;
-            if (best < 0 || items[p].rows.size() > items[best].rows.size()) best = (int64_t)p;
+            if (best < 0 || items[p].n_path > items[best].n_path) best = (int64_t)p;
         }
         pick[r] = best;
         if (best >= 0) {
@@ -477,7 +479,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         for (size_t t = 0; t < it.gnodes.size(); t++)
             if (t == 0 || it.gnodes[t] != it.gnodes[t - 1])  // align.rs:1120-1123
                 res->path_handles[o++] = on_device ? store.of(p).h_handles[store.off[p].node0 + it.gnodes[t]] : SG[p].handles[it.gnodes[t]];
-        res->path_length[r] = (uint32_t)it.rows.size();
+        res->path_length[r] = it.n_path;
         res->path_start[r] = it.start_off;
         res->path_end[r] = it.end_off;
         res->block_length[r] = it.aligned;
@@ -492,6 +494,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     res->ms_subgraph = (float)sub_ms;  // GPU kernels before the first DP launch (VGA_SUBGRAPH=host: host threads, overlapped with the GPU)
     res->ms_dp = tm.ms_dp;
     res->ms_traceback = tm.ms_tb;
+    res->result_bytes = tm.result_bytes;
     res->ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     tr.mark("assemble records");
     if (tr.on && !on_device) {

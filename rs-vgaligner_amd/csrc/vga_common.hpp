@@ -10,13 +10,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/vga_hip.h"
 
-#define VGA_ABI_VERSION 5
+#define VGA_ABI_VERSION 6
 
 struct vga_dev_index {
     uint32_t k = 0;
@@ -53,10 +54,21 @@ struct vga_timer_entry {
     hipStream_t stream;  // the stream both events are recorded on
 };
 
+struct vga_deferred { void *dev, *pinned, *reg; size_t reg_bytes; };
+
 struct vga_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    std::string err;
+    std::string err;     // written by vga_set_error, copied out by vga_last_error, both under err_mu (two entry points of one
+    std::mutex err_mu;   // context may run on two threads: vga_chain_paths_text beside vga_align_batch)
+    // settings of this context (vga_ctx_set_*): a share of the GPU's memory for contexts that share a device, and the host
+    // threads its calls fan out to (0: VGA_HOST_THREADS, else the hardware's, at most 32)
+    double pool_fraction = 1.0;
+    unsigned host_threads = 0;
+    // memory that grown buffers of THIS context gave up while launches were in flight (vga_defer_release): released by the next
+    // entry point that starts on this context while it is idle, and with the context
+    std::mutex deferred_mu;
+    std::vector<vga_deferred> deferred;
     vga_dev_index index;
     // per-call kernel timing (events recorded on `stream`)
     std::vector<vga_timer_entry> timers;
@@ -109,10 +121,19 @@ int vga_set_error(vga_ctx *ctx, int code, const char *fmt, ...);
 
 // hipFree and hipHostFree wait for every kernel that runs on the device.  A buffer that has to grow while launches are in flight
 // (a sub-batch's staging beside a DP launch that runs for a second) would stall the launch path for as long: it hands its old
-// memory to this list instead, which is released by the next call that starts on an idle context (vga_release_deferred: the
-// entry points of map / align / poa) and with the context.
+// memory to the list of the context the calling thread works for (vga_current_ctx: set by the entry points, inherited by the
+// threads they start), which that context's next entry point releases while it is idle (vga_release_deferred) -- never another
+// context's, whose launches may be in flight -- and vga_ctx_destroy.  Outside any context the memory is released at once.
 void vga_defer_release(void *device_ptr, void *pinned_ptr, void *registered_ptr, size_t registered_bytes);
-void vga_release_deferred();
+void vga_release_deferred(vga_ctx *ctx);
+vga_ctx *vga_current_ctx();
+struct vga_ctx_scope {  // the context the calling thread works for, for the lifetime of the object
+    vga_ctx *prev;
+    explicit vga_ctx_scope(vga_ctx *ctx);
+    ~vga_ctx_scope();
+    vga_ctx_scope(const vga_ctx_scope &) = delete;
+    vga_ctx_scope &operator=(const vga_ctx_scope &) = delete;
+};
 
 // grow-only device buffer
 template <typename T>
@@ -201,7 +222,8 @@ struct vga_trace {
     }
 };
 
-// host thread fan-out (VGA_HOST_THREADS caps it; default: hardware concurrency, at most 32)
+// host thread fan-out: the current context's setting (vga_ctx_set_host_threads), else VGA_HOST_THREADS, else the hardware's
+// concurrency, at most 32
 unsigned vga_host_threads(uint64_t n);
 template <typename F>
 void vga_parallel_for(uint64_t n, F f, unsigned max_threads = 0)  // max_threads: a cap for small jobs (starting 32 threads costs ~0.7 ms)
@@ -210,8 +232,9 @@ void vga_parallel_for(uint64_t n, F f, unsigned max_threads = 0)  // max_threads
     if (max_threads && nt > max_threads) nt = max_threads;
     if (nt <= 1) { for (uint64_t i = 0; i < n; i++) f(i); return; }
     std::vector<std::thread> th;
+    vga_ctx *const cur = vga_current_ctx();
     for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([&, t]() { for (uint64_t i = t; i < n; i += nt) f(i); });
+        th.emplace_back([&, t]() { vga_ctx_scope scope(cur); for (uint64_t i = t; i < n; i += nt) f(i); });
     for (auto &x : th) x.join();
 }
 

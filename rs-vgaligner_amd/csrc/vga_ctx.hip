@@ -20,7 +20,7 @@ int vga_set_error(vga_ctx *ctx, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    if (ctx) { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->err = buf; }
     return code;
 }
 
@@ -31,6 +31,8 @@ unsigned vga_host_threads(uint64_t n)
     if (nt > 32) nt = 32;
     const char *e = getenv("VGA_HOST_THREADS");
     if (e && atoi(e) > 0) nt = (unsigned)atoi(e);
+    if (const vga_ctx *c = vga_current_ctx())
+        if (c->host_threads) nt = c->host_threads;
     if ((uint64_t)nt > n) nt = (unsigned)(n ? n : 1);
     return nt;
 }
@@ -38,38 +40,73 @@ unsigned vga_host_threads(uint64_t n)
 extern "C" int vga_abi_version(void) { return VGA_ABI_VERSION; }
 
 namespace {
-struct deferred_t { void *dev, *pinned, *reg; size_t reg_bytes; int device; };
-std::mutex g_deferred_mu;
-std::vector<deferred_t> g_deferred;
+thread_local vga_ctx *t_current_ctx = nullptr;
+void release_one(const vga_deferred &d)
+{
+    if (d.dev) (void)hipFree(d.dev);
+    if (d.pinned) (void)hipHostFree(d.pinned);
+    if (d.reg) { (void)hipHostUnregister(d.reg); (void)munmap(d.reg, d.reg_bytes); }
+}
 }  // namespace
+
+vga_ctx *vga_current_ctx() { return t_current_ctx; }
+vga_ctx_scope::vga_ctx_scope(vga_ctx *ctx) : prev(t_current_ctx) { t_current_ctx = ctx; }
+vga_ctx_scope::~vga_ctx_scope() { t_current_ctx = prev; }
 
 void vga_defer_release(void *device_ptr, void *pinned_ptr, void *registered_ptr, size_t registered_bytes)
 {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(g_deferred_mu);
-    g_deferred.push_back({device_ptr, pinned_ptr, registered_ptr, registered_bytes, dev});
+    const vga_deferred d = {device_ptr, pinned_ptr, registered_ptr, registered_bytes};
+    vga_ctx *ctx = t_current_ctx;
+    if (!ctx) { release_one(d); return; }  // (no context to keep it for: the old behaviour, a release that waits for the device)
+    std::lock_guard<std::mutex> lk(ctx->deferred_mu);
+    ctx->deferred.push_back(d);
 }
 
-void vga_release_deferred()
+// the calling context is idle (an entry point that has not launched anything yet, or its destruction): what ITS buffers gave up
+// goes back now.  Other contexts' lists are theirs: a hipFree here would wait for their launches, and stall them.
+void vga_release_deferred(vga_ctx *ctx)
 {
-    std::vector<deferred_t> todo;
+    if (!ctx) return;
+    std::vector<vga_deferred> todo;
     {
-        std::lock_guard<std::mutex> lk(g_deferred_mu);
-        todo.swap(g_deferred);
+        std::lock_guard<std::mutex> lk(ctx->deferred_mu);
+        todo.swap(ctx->deferred);
     }
     if (todo.empty()) return;
     int cur = 0;
     (void)hipGetDevice(&cur);
-    for (const deferred_t &d : todo) {
-        if (d.dev) { (void)hipSetDevice(d.device); (void)hipFree(d.dev); }
-        if (d.pinned) (void)hipHostFree(d.pinned);
-        if (d.reg) { (void)hipHostUnregister(d.reg); (void)munmap(d.reg, d.reg_bytes); }
-    }
-    (void)hipSetDevice(cur);
+    if (cur != ctx->device) (void)hipSetDevice(ctx->device);
+    for (const vga_deferred &d : todo) release_one(d);
+    if (cur != ctx->device) (void)hipSetDevice(cur);
 }
 
-extern "C" const char *vga_last_error(const vga_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+extern "C" int vga_ctx_set_pool_fraction(vga_ctx *ctx, double fraction)
+{
+    if (!ctx) return VGA_ERR_ARG;
+    if (!(fraction > 0.0) || fraction > 1.0) return vga_set_error(ctx, VGA_ERR_ARG, "vga_ctx_set_pool_fraction: %g is not in (0, 1]", fraction);
+    ctx->pool_fraction = fraction;
+    return VGA_OK;
+}
+
+extern "C" int vga_ctx_set_host_threads(vga_ctx *ctx, uint32_t n_threads)
+{
+    if (!ctx) return VGA_ERR_ARG;
+    if (n_threads > 1024) return vga_set_error(ctx, VGA_ERR_ARG, "vga_ctx_set_host_threads: %u threads", n_threads);
+    ctx->host_threads = n_threads;
+    return VGA_OK;
+}
+
+extern "C" const char *vga_last_error(const vga_ctx *ctx)
+{
+    if (!ctx) return "null ctx";
+    // a copy taken under the lock, kept per calling thread: the pointer stays valid until this thread asks again
+    static thread_local std::string copy;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<vga_ctx *>(ctx)->err_mu);
+        copy = ctx->err;
+    }
+    return copy.c_str();
+}
 
 extern "C" int vga_ctx_create(int device, vga_ctx **out)
 {
@@ -120,6 +157,7 @@ extern "C" void vga_ctx_destroy(vga_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    vga_ctx_scope scope(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (vga_batch *b : ctx->batches) {
         if (b->d_reads) (void)hipFree(b->d_reads);
@@ -135,7 +173,7 @@ extern "C" void vga_ctx_destroy(vga_ctx *ctx)
     vga_index_release(ctx->index);
     for (hipEvent_t ev : ctx->event_pool) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    vga_release_deferred();
+    vga_release_deferred(ctx);
     delete ctx;
 }
 

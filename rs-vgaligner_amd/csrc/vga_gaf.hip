@@ -218,6 +218,7 @@ static int vga_chain_paths_text_impl(vga_ctx *ctx, const vga_map_result *m, vga_
 extern "C" int vga_chain_paths_text(vga_ctx *ctx, const vga_map_result *chains, vga_chain_text **out)
 {
     try {
+        vga_ctx_scope scope(ctx);  // (buffers that grow here give their memory to this context's list; map / align entry points release it)
         return vga_chain_paths_text_impl(ctx, chains, out);
     } catch (const std::bad_alloc &) {
         return vga_set_error(ctx, VGA_ERR_NOMEM, "vga_chain_paths_text: out of host memory");

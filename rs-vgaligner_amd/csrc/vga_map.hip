@@ -452,7 +452,8 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
     vga_ctx *ctx = b->ctx;
     *out = nullptr;
     (void)hipSetDevice(ctx->device);
-    vga_release_deferred();  // (buffers that grew during an earlier call: freed now, while this context has nothing in flight)
+    vga_ctx_scope scope(ctx);
+    vga_release_deferred(ctx);  // (buffers of this context that grew during an earlier call: freed now, while it has nothing in flight)
     if (!ctx->index.loaded) return vga_set_error(ctx, VGA_ERR_NO_INDEX, "vga_map_batch: no index uploaded");
     // only_forward = 0 (anchors_for_query(..., false), src/chain.rs:154-155): every k-mer record becomes an anchor; the
     // orientation of each end travels in bit 31 of target_begin / target_end.  vga_align_batch accepts forward chains only.

@@ -39,6 +39,7 @@
 #include "vga_poa_t4.hpp"
 #include "vga_poa_t5.hpp"
 #include "vga_poa_t6.hpp"
+#include "vga_poa_text.hpp"
 
 // One workgroup per staged problem: copies its node table, predecessor rows, sink rows, bases and query from the device
 // store of vga_subgraph.hip (and the batch's reads) to where this sub-batch's poa_prob says they are.
@@ -182,11 +183,20 @@ struct poa_slot {
     vga_hbuf<char> h_q;
     // results come back into one of two sets, alternating per use of the slot: the host is still reading set A of the
     // sub-batch that just finished when the next sub-batch on this slot is enqueued (it will write set B)
+    // k_poa_text: cs / CIGAR / node path of every problem as text in a compact arena (claimed through d_tcur), one record each
+    vga_dbuf<char> d_text;
+    vga_dbuf<poa_text_out> d_touts;
+    vga_dbuf<unsigned long long> d_tcur;
     struct out_set {
         vga_hbuf<uint32_t> h_orow;
         vga_hbuf<uint8_t> h_ops;
         vga_hbuf<char> h_seq;     // device store: the bases of the sub-batch's problems (row r of a problem is byte seq0 + r - 1)
         vga_hbuf<poa_out> h_outs;
+        vga_hbuf<char> h_text;
+        vga_hbuf<poa_text_out> h_touts;
+        vga_hbuf<unsigned long long> h_tcur;
+        bool text = false;        // this sub-batch's strings were written on the device
+        uint64_t tot_ops = 0, tot_seq = 0;
     } outs[2];
     uint32_t uses = 0;
 };
@@ -348,6 +358,7 @@ extern "C" int vga_align_prepare(vga_ctx *ctx, uint64_t n_reads, uint32_t max_re
     if (getenv("VGA_POA_ARENAS") && atoi(getenv("VGA_POA_ARENAS")) == 0) return VGA_OK;  // (classic mode sizes its pool itself)
     if (4ull * ((uint64_t)max_read_len + 8) > POA_CHUNK) return VGA_OK;
     if (hipSetDevice(ctx->device) != hipSuccess) return vga_set_error(ctx, VGA_ERR_HIP, "vga_align_prepare: hipSetDevice failed");
+    vga_ctx_scope scope(ctx);
     if (!ctx->poa_ws) {
         ctx->poa_ws = new poa_ws();
         ctx->poa_ws_free = [](void *q) { delete (poa_ws *)q; };
@@ -357,8 +368,10 @@ extern "C" int vga_align_prepare(vga_ctx *ctx, uint64_t n_reads, uint32_t max_re
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return VGA_OK;
     uint64_t avail = free_b > (16ull << 30) ? (uint64_t)((double)free_b * 0.85) : free_b / 4;
-    if (const char *fr = getenv("VGA_POOL_FRACTION")) {
-        const double f = atof(fr);
+    {
+        // contexts that share a GPU: vga_ctx_set_pool_fraction (the driver: 1 / their number); VGA_POOL_FRACTION is the diagnostic override
+        double f = ctx->pool_fraction;
+        if (const char *fr = getenv("VGA_POOL_FRACTION")) f = atof(fr);
         if (f > 0.0 && f < 1.0) avail = (uint64_t)((double)avail * f);
     }
     if (const char *env_pool = getenv("VGA_POOL_BYTES")) avail = std::min<uint64_t>(avail, strtoull(env_pool, nullptr, 10));
@@ -533,9 +546,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         have += W.classic_size;
         const uint64_t reserve = std::max<uint64_t>((uint64_t)((double)have * 0.15), 16ull << 30);
         avail_pool = have > reserve ? have - reserve : have / 4;
-        // several contexts on one GPU (vgaligner map --devices 0,0: the driver sets this to 1 / their number) share it
-        if (const char *fr = getenv("VGA_POOL_FRACTION")) {
-            const double f = atof(fr);
+        // several contexts on one GPU (vgaligner map --devices 0,0: the driver sets each one's share to 1 / their number) share it
+        {
+            double f = ctx->pool_fraction;
+            if (const char *fr = getenv("VGA_POOL_FRACTION")) f = atof(fr);
             if (f > 0.0 && f < 1.0) avail_pool = (uint64_t)((double)avail_pool * f);
         }
         if (const char *env_pool = getenv("VGA_POOL_BYTES")) avail_pool = std::min<uint64_t>(avail_pool, strtoull(env_pool, nullptr, 10));
@@ -692,6 +706,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     if (n_arenas && !getenv("VGA_POOL_NOPOLL"))
         keeper.t = std::thread([&]() {
             (void)hipSetDevice(ctx->device);
+            vga_ctx_scope scope(ctx);
             while (!keeper.stop) {
                 (void)list_new_segments();
                 std::this_thread::sleep_for(std::chrono::milliseconds(1));
@@ -822,14 +837,19 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             out[p].n_rows = g.N;
         }
         const bool dev = feed.dev != nullptr;
+        // cs / CIGAR / node path on the device (K4c) when the caller does not need the per-base rows; VGA_POA_TEXT=host keeps the host's
+        const bool text_on_device = dev && !feed.want_rows && !(getenv("VGA_POA_TEXT") && strstr(getenv("VGA_POA_TEXT"), "host"));
         chk(S.h_probs.reserve(nb));
         if (dev) chk(S.h_ids.reserve(2 * (size_t)nb));
         else {
             chk(S.h_ntab.reserve(tot_nodes)); chk(S.h_seq32.reserve(tot_seq / 4 + 1));
             chk(S.h_preds.reserve(tot_preds + 1)); chk(S.h_sink.reserve(tot_sink + 1)); chk(S.h_q.reserve(tot_q + 1));
         }
-        chk(O.h_ops.reserve(tot_ops)); chk(O.h_orow.reserve(tot_ops)); chk(O.h_outs.reserve(nb));
-        if (feed.dev) chk(O.h_seq.reserve(tot_seq + 4));
+        chk(O.h_outs.reserve(nb));
+        if (!text_on_device) {  // (K4c: the operations stay on the device; the fallback reserves these when it needs them)
+            chk(O.h_ops.reserve(tot_ops)); chk(O.h_orow.reserve(tot_ops));
+            if (feed.dev) chk(O.h_seq.reserve(tot_seq + 4));
+        }
         chk(S.d_probs.reserve(nb)); chk(S.d_ntab.reserve(tot_nodes)); chk(S.d_seq32.reserve(tot_seq / 4 + 1));
         chk(S.d_preds.reserve(tot_preds + 1)); chk(S.d_sink.reserve(tot_sink + 1)); chk(S.d_q.reserve(tot_q + 1));
         chk(S.d_rows.reserve(tot_rows)); chk(S.d_outs.reserve(nb)); chk(S.d_ops.reserve(tot_ops)); chk(S.d_orow.reserve(tot_ops));
@@ -1044,11 +1064,31 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         vga_timer_end(ctx, t_tb);
         chk(hipMemcpyAsync(O.h_outs.p, S.d_outs.p, nb * sizeof(poa_out), hipMemcpyDeviceToHost, st));
         chk(hipMemcpyAsync(W.h_next.p + slot, W.d_next.p + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        chk(hipMemcpyAsync(O.h_ops.p, S.d_ops.p, tot_ops, hipMemcpyDeviceToHost, st));
-        chk(hipMemcpyAsync(O.h_orow.p, S.d_orow.p, tot_ops * 4, hipMemcpyDeviceToHost, st));
-        // (device store: the cs strings need the graph bases of the aligned rows -- the gathered node sequences come back too,
-        // 17 KB per problem, instead of a handle lookup per aligned base)
-        if (feed.dev) chk(hipMemcpyAsync(O.h_seq.p, S.d_seq32.p, tot_seq, hipMemcpyDeviceToHost, st));
+        O.text = text_on_device;
+        O.tot_ops = tot_ops; O.tot_seq = tot_seq;
+        if (text_on_device) {
+            // K4c: the strings and the node path are written where the operations are (vga_poa_text.hpp); what crosses PCIe now is a
+            // record per problem and the counter of the arena -- the text itself follows when the host knows how much there is
+            const uint64_t arena = std::min<uint64_t>(2ull * tot_ops + 64ull * nb + 4096ull, 0xF0000000ull);
+            chk(S.d_text.reserve(arena)); chk(S.d_touts.reserve(nb)); chk(S.d_tcur.reserve(1));
+            chk(O.h_touts.reserve(nb)); chk(O.h_tcur.reserve(1));
+            if (launch_err == hipSuccess) {
+                int t_tx = vga_timer_begin(ctx, "poa_text", 0, st);
+                chk(hipMemsetAsync(S.d_tcur.p, 0, sizeof(unsigned long long), st));
+                hipLaunchKernelGGL(k_poa_text, dim3(nb), dim3(64), 0, st, nb, S.d_probs.p, S.d_outs.p, S.d_ops.p, S.d_orow.p, S.d_rows.p, S.d_ntab.p,
+                                   (const char *)S.d_seq32.p, S.d_q.p, S.d_text.p, (uint32_t)arena, S.d_tcur.p, S.d_touts.p);
+                chk(hipGetLastError());
+                vga_timer_end(ctx, t_tx);
+                chk(hipMemcpyAsync(O.h_touts.p, S.d_touts.p, nb * sizeof(poa_text_out), hipMemcpyDeviceToHost, st));
+                chk(hipMemcpyAsync(O.h_tcur.p, S.d_tcur.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            }
+        } else {
+            chk(hipMemcpyAsync(O.h_ops.p, S.d_ops.p, tot_ops, hipMemcpyDeviceToHost, st));
+            chk(hipMemcpyAsync(O.h_orow.p, S.d_orow.p, tot_ops * 4, hipMemcpyDeviceToHost, st));
+            // (device store: the cs strings need the graph bases of the aligned rows -- the gathered node sequences come back too,
+            // 17 KB per problem, instead of a handle lookup per aligned base)
+            if (feed.dev) chk(hipMemcpyAsync(O.h_seq.p, S.d_seq32.p, tot_seq, hipMemcpyDeviceToHost, st));
+        }
         return {i0, i1, raw_est, slot, oset, false, arena};
     };
     // host: CIGAR / cs / node path of one problem from the raw op stream (reverse order on the device)
@@ -1064,6 +1104,18 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         if (!it.ok) return;
         const poa_prep &g = G[p];
         const poa_prob &pb = probs[p];
+        if (S.text && S.h_touts.p[i - i0].flags == 1u) {
+            // K4c wrote the fields (vga_poa_text.hpp): they are copied, not derived
+            const poa_text_out &t = S.h_touts.p[i - i0];
+            it.cs.assign(S.h_text.p + t.cs_off, t.cs_len);
+            it.cigar.assign(S.h_text.p + t.cg_off, t.cg_len);
+            const uint32_t *runs = (const uint32_t *)(S.h_text.p + t.runs_off);
+            it.gnodes.assign(runs, runs + t.n_runs);
+            it.rows.clear();
+            it.deduped = true;
+            it.n_path = t.n_path; it.start_off = t.start_off; it.end_off = t.end_off; it.aligned = t.aligned;
+            return;
+        }
         const uint8_t *po = S.h_ops.p + pb.ops0;
         const uint32_t *pr = S.h_orow.p + pb.ops0;
         const char *q = views[p].query;
@@ -1133,6 +1185,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         it.cs.assign(cs0, (size_t)(c - cs0));
         it.cigar.assign(cg0, (size_t)(d - cg0));
         it.rows.assign(rowp, rowp + n_rows);
+        it.n_path = n_rows;
+        it.deduped = false;
         it.aligned = (uint32_t)aligned;
         // rows ascend along the path: merge-walk the node table to label them
         it.gnodes.resize(it.rows.size());
@@ -1161,6 +1215,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     std::vector<sub_t> inflight;
     bool slot_busy[POA_SLOTS] = {};
     uint64_t all_cells = 0, all_vcells = 0, all_rows = 0, all_q = 0, all_ops = 0;
+    uint64_t text_bytes = 0;  // what came back over PCIe for the strings and paths: K4c's text, or the raw operations
     auto fill = [&]() {
         while ((int)inflight.size() < n_slots && !todo.empty() && !malformed && !dev_failed && launch_err == hipSuccess) {
             int slot = 0;
@@ -1203,8 +1258,32 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             if (tr.on) fprintf(stderr, "[vga-trace] poa: (at %.1f ms) the launch of [%llu, %llu) has finished\n",
                                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), (unsigned long long)cur.i0, (unsigned long long)cur.i1);
         }
-        const poa_slot::out_set &S = W.slot[cur.slot].outs[cur.oset];
+        poa_slot::out_set &S = W.slot[cur.slot].outs[cur.oset];
         if (launch_err != hipSuccess) break;
+        if (S.text) {
+            // K4c, second half: the text the kernel wrote (its length is known now); problems that found the arena full fall back
+            // to the operations, which are still on the device
+            poa_slot &SL = W.slot[cur.slot];
+            const uint64_t used = std::min<uint64_t>(S.h_tcur.p[0], SL.d_text.cap);
+            bool overflow = false;
+            for (uint64_t i = cur.i0; i < cur.i1; i++) overflow = overflow || S.h_touts.p[i - cur.i0].flags == 2u;
+            hipError_t ce = S.h_text.reserve(used + 16);
+            if (ce == hipSuccess && used) ce = hipMemcpyAsync(S.h_text.p, SL.d_text.p, used, hipMemcpyDeviceToHost, sarr[cur.slot]);
+            if (ce == hipSuccess && overflow) {
+                if (tr.on) fprintf(stderr, "[vga-trace] poa:   the text arena was too small for some problems: their operations come back\n");
+                ce = S.h_ops.reserve(S.tot_ops);
+                if (ce == hipSuccess) ce = S.h_orow.reserve(S.tot_ops);
+                if (ce == hipSuccess) ce = S.h_seq.reserve(S.tot_seq + 4);
+                if (ce == hipSuccess) ce = hipMemcpyAsync(S.h_ops.p, SL.d_ops.p, S.tot_ops, hipMemcpyDeviceToHost, sarr[cur.slot]);
+                if (ce == hipSuccess) ce = hipMemcpyAsync(S.h_orow.p, SL.d_orow.p, S.tot_ops * 4, hipMemcpyDeviceToHost, sarr[cur.slot]);
+                if (ce == hipSuccess) ce = hipMemcpyAsync(S.h_seq.p, SL.d_seq32.p, S.tot_seq, hipMemcpyDeviceToHost, sarr[cur.slot]);
+            }
+            if (ce == hipSuccess) ce = hipStreamSynchronize(sarr[cur.slot]);
+            if (ce != hipSuccess) { launch_err = ce; break; }
+            text_bytes += used + (cur.i1 - cur.i0) * sizeof(poa_text_out);
+            if (overflow) text_bytes += 5 * S.tot_ops + S.tot_seq;
+        } else
+            text_bytes += 5 * S.tot_ops + (feed.dev ? S.tot_seq : 0);
         bool pool_fail = false;
         for (uint64_t i = cur.i0; i < cur.i1; i++)
             if (S.h_outs.p[i - cur.i0].status == POA_ST_POOL) {
@@ -1362,6 +1441,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     tm.ms_dp = vga_timer_sum(ctx, "poa_band_dp");
     tm.ms_tb = vga_timer_sum(ctx, "poa_traceback");
     tm.ms_total = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+    tm.result_bytes = text_bytes;
 #undef POA_CHECK
     return VGA_OK;
 }
@@ -1384,7 +1464,8 @@ static int vga_poa_batch_impl(vga_ctx *ctx, uint64_t n, const uint64_t *node_ptr
         return VGA_ERR_ARG;
     *out = nullptr;
     (void)hipSetDevice(ctx->device);
-    vga_release_deferred();  // (buffers that grew during an earlier call: freed now, while this context has nothing in flight)
+    vga_ctx_scope scope(ctx);
+    vga_release_deferred(ctx);  // (buffers of this context that grew during an earlier call: freed now, while it has nothing in flight)
     poa_feed feed;
     std::vector<poa_view> &views = feed.views;
     views.resize(n);

@@ -26,6 +26,9 @@ struct poa_item {
     int32_t score = 0;
     uint32_t start_off = 0, end_off = 0, aligned = 0;
     uint64_t n_rows = 0, n_cells = 0, n_vcells = 0;
+    uint32_t n_path = 0;           // abpoa_nodes.len(): graph-consuming alignment columns
+    bool deduped = false;          // the fields came from the device (k_poa_text): `rows` is empty and `gnodes` holds every node the
+                                   // alignment enters once, in order (graph_nodes.dedup(), align.rs:1114) -- vga_align_batch's input
     std::vector<uint32_t> rows;    // AbpoaAlignmentResult.abpoa_nodes: 1-based base-row id per graph-consuming column
     std::vector<uint32_t> gnodes;  // AbpoaAlignmentResult.graph_nodes
     std::string cigar, cs;
@@ -33,6 +36,7 @@ struct poa_item {
 
 struct poa_timing {
     float ms_dp = 0, ms_tb = 0, ms_total = 0;
+    uint64_t result_bytes = 0;  // bytes copied back for strings and node paths (K4c's text, or the raw operations)
 };
 
 // How poa_run obtains its problems.  `views` has one entry per problem with query / qlen valid.  When `prepare` is
@@ -53,6 +57,7 @@ struct poa_feed {
     // (1 = very long: such problems are launched apart, with the largest workgroup and window)
     const uint32_t *order = nullptr;
     const uint8_t *klass = nullptr;
+    bool want_rows = true;    // false (vga_align_batch): cs, CIGAR and the deduplicated node path may come from the device (k_poa_text)
     bool keep_timers = false;  // the caller has reset the context's kernel timers and recorded some of its own
 };
 

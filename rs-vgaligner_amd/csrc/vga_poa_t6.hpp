@@ -5,6 +5,8 @@
 //     CPL at or below the band's first column; H words and G bytes of the row above live in 3 CPL / 2 vector registers.  When
 //     the anchor moves (every CPL rows while the band slides along the diagonal) the state moves across lanes: one DPP
 //     wave_shl per register for the common step of one lane, ds_bpermute for anything else;
+//   * a row wider than the window (config 5: one problem in eight has a stretch of them) runs a SECOND STEP of the same code on
+//     a second register set that continues the window (128 virtual lanes); the scan totals of the first step are its carry;
 //   * no barriers, no LDS row, no cross-wave scan: the max-plus scan of a row is the lane's serial scan, one DPP wave scan and
 //     one wave_shr; the row maximum is a DPP reduction and two ballots;
 //   * every row is written CLEAN: cells outside [beg, end] leave the row far below every real score, so no row ever masks what
@@ -14,7 +16,7 @@
 //     virtual predecessor row of k_poa_dp_t5's staging pass straight into the registers from the predecessors' value rows;
 //   * the row loop's scalar state is small enough to stay in scalar registers (k_poa_dp_t5 keeps ~200 scalars alive and
 //     pays ~45 v_readlane / v_writelane per wave and row for the ones that spill).
-// What it does not do is handed back with POA_ST_RETRY and runs in k_poa_dp_t5: a row whose band does not fit the window,
+// What it does not do is handed back with POA_ST_RETRY and runs in k_poa_dp_t5: a row whose band does not fit two windows,
 // a query with characters other than A / C / G / T, anything outside chunk-pool mode.
 #pragma once
 
@@ -136,23 +138,28 @@ __global__ __launch_bounds__(64) void k_poa_dp_t6(const poa_prob *__restrict__ p
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const bool q_plain = __builtin_amdgcn_ballot_w64(non_acgt != 0) == 0;
-    // a row of this kernel never has more than WIN + 4 storage columns: the ring's slots are sized for that
-    const uint32_t ring_size = (6u * (uint32_t)(WIN + 8) + 15u) & ~15u;
+    // a row of this kernel never has more than 2 WIN + 4 storage columns: the ring's slots are sized for that
+    const uint32_t ring_size = (6u * (uint32_t)(2 * WIN + 8) + 15u) & ~15u;
     const uint64_t ring_base = state_lo;
     if ((uint64_t)ring_size * ring_rows > A.cp.state_size || !q_plain) { failed = true; status = POA_ST_RETRY; }
     uint32_t ring_head = 0;
 
-    // ---- the row above, in registers: lane l holds columns wbase + CPL l .. + CPL - 1
-    int H[Q][4];       // cell words 4 H + 1
-    uint32_t Ga[Q], Gb[Q];  // G1 | G2 << 8 of cells 0, 1 / 2, 3 of each quad
-    uint32_t qn[Q];    // the column codes of the lane's quads (they only change when the window moves)
+    // ---- the row above, in registers: lane l of set s holds columns wbase + CPL (64 s + l) .. + CPL - 1.  Set 0 is the window
+    // every row runs in; set 1 continues it for the rows that are wider (a second step of the same code): it only holds anything
+    // while b_live
+    int H[2][Q][4];             // cell words 4 H + 1
+    uint32_t Ga[2][Q], Gb[2][Q];  // G1 | G2 << 8 of cells 0, 1 / 2, 3 of each quad
+    uint32_t qn[2][Q];          // the column codes of the lane's quads (they only change when the window moves)
 #pragma unroll
-    for (int q = 0; q < Q; q++) {
-        qn[q] = 0; Ga[q] = 0; Gb[q] = 0;
+    for (int s = 0; s < 2; s++)
 #pragma unroll
-        for (int k = 0; k < 4; k++) H[q][k] = T4_NEG + 1;
-    }
-    int wbase = 0;  // first column of the window the registers hold (a multiple of CPL); -1 forces the codes to be loaded
+        for (int q = 0; q < Q; q++) {
+            qn[s][q] = 0; Ga[s][q] = 0; Gb[s][q] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) H[s][q][k] = T4_NEG + 1;
+        }
+    bool b_live = false;
+    int wbase = 0;  // first column of the window the registers hold (a multiple of CPL)
     bool have_codes = false;
     const int lane_e1 = 4 * e1 * CPL * lane, lane_e2 = 4 * e2 * CPL * lane;  // a-space offset of the lane's first column in its window
 
@@ -215,7 +222,8 @@ __global__ __launch_bounds__(64) void k_poa_dp_t6(const poa_prob *__restrict__ p
         const int bal = beg & ~3;
         const int W = (end - bal + 1 + 3) & ~3;
         const int nbase = (int)((uint32_t)beg / (uint32_t)CPL) * CPL;  // the window this row needs
-        if (end - nbase >= WIN) { failed = true; status = POA_ST_RETRY; break; }
+        if (end - nbase >= 2 * WIN) { failed = true; status = POA_ST_RETRY; break; }
+        const bool two = end - nbase >= WIN;  // a second step
         const uint64_t doff = alloc((uint32_t)W * (np > 1 ? 4u : 1u));
         uint64_t voff = 0;
         if (last && !failed) {
@@ -245,36 +253,71 @@ __global__ __launch_bounds__(64) void k_poa_dp_t6(const poa_prob *__restrict__ p
         const int gsh = (int)((gb >> 1) & 3u);
         const int ne4t = 4 * sc_ne + 1, mm4 = 4 * (sc_eq - sc_ne);
 
-        const int jl = nbase + CPL * lane;  // the lane's first column
         POA_MARK("t6_state");
-        int hp0;  // the predecessor's word at column jl - 1
-        int htt[Q][4], e1t[Q][4], e2t[Q][4];
-
+        int hp0[2];  // the predecessor's word at the column left of the lane's first, per set
+        hp0[1] = T4_NEG + 1;
+        if (two && !b_live) {
+            // the second set comes into use: nothing of the row above lies there
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                Ga[1][q] = 0; Gb[1][q] = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) H[1][q][k] = T4_NEG + 1;
+            }
+            b_live = true;
+        }
         if (__builtin_expect(simple, 1)) {
             // ---- the row above is in the registers: move it if the window moves
-            hp0 = t4_shr1_mov(H[Q - 1][3], T4_NEG + 1);
+            hp0[0] = t4_shr1_mov(H[0][Q - 1][3], T4_NEG + 1);
+            if (b_live) hp0[1] = t4_shr1_mov(H[1][Q - 1][3], __builtin_amdgcn_readlane(H[0][Q - 1][3], 63));
             const int dl = (nbase - wbase) / CPL;
             if (dl != 0) {
-                if (dl == 1) {
-                    hp0 = t6_shl1(hp0, T4_NEG + 1);
+                if (dl == 1 && !b_live) {
+                    hp0[0] = t6_shl1(hp0[0], T4_NEG + 1);
 #pragma unroll
                     for (int q = 0; q < Q; q++) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) H[q][k] = t6_shl1(H[q][k], T4_NEG + 1);
-                        Ga[q] = (uint32_t)t6_shl1((int)Ga[q], 0);
-                        Gb[q] = (uint32_t)t6_shl1((int)Gb[q], 0);
+                        for (int k = 0; k < 4; k++) H[0][q][k] = t6_shl1(H[0][q][k], T4_NEG + 1);
+                        Ga[0][q] = (uint32_t)t6_shl1((int)Ga[0][q], 0);
+                        Gb[0][q] = (uint32_t)t6_shl1((int)Gb[0][q], 0);
+                    }
+                } else if (dl == 1) {
+                    // lane 63 of the first set takes over lane 0 of the second
+                    hp0[0] = t6_shl1(hp0[0], __builtin_amdgcn_readlane(hp0[1], 0));
+                    hp0[1] = t6_shl1(hp0[1], T4_NEG + 1);
+#pragma unroll
+                    for (int q = 0; q < Q; q++) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            H[0][q][k] = t6_shl1(H[0][q][k], __builtin_amdgcn_readlane(H[1][q][k], 0));
+                            H[1][q][k] = t6_shl1(H[1][q][k], T4_NEG + 1);
+                        }
+                        Ga[0][q] = (uint32_t)t6_shl1((int)Ga[0][q], __builtin_amdgcn_readlane((int)Ga[1][q], 0));
+                        Gb[0][q] = (uint32_t)t6_shl1((int)Gb[0][q], __builtin_amdgcn_readlane((int)Gb[1][q], 0));
+                        Ga[1][q] = (uint32_t)t6_shl1((int)Ga[1][q], 0);
+                        Gb[1][q] = (uint32_t)t6_shl1((int)Gb[1][q], 0);
                     }
                 } else {
-                    const int src = lane + dl;
-                    const bool in = src >= 0 && src < 64;
-                    const int sb = (src & 63) << 2;
-                    hp0 = t6_shift(hp0, T4_NEG + 1, sb, in);
+                    // any distance: lane l of set s takes what virtual lane 64 s + l + dl held (of 128, the second set only if live)
+                    const int s0 = lane + dl, s1 = lane + 64 + dl;
+                    const int sb0 = (s0 & 63) << 2, sb1 = (s1 & 63) << 2;
+                    const int w0 = s0 >> 6, w1 = s1 >> 6;  // 0: first set, 1: second set, anything else: outside
+                    const bool live = b_live;
+                    auto move = [&](int &a, int &b, int fill) {
+                        const int a0 = __builtin_amdgcn_ds_bpermute(sb0, a), a1 = __builtin_amdgcn_ds_bpermute(sb1, a);
+                        int b0 = fill, b1 = fill;
+                        if (live) { b0 = __builtin_amdgcn_ds_bpermute(sb0, b); b1 = __builtin_amdgcn_ds_bpermute(sb1, b); }
+                        a = w0 == 0 ? a0 : (w0 == 1 ? b0 : fill);
+                        b = w1 == 0 ? a1 : (w1 == 1 ? b1 : fill);
+                    };
+                    move(hp0[0], hp0[1], T4_NEG + 1);
 #pragma unroll
                     for (int q = 0; q < Q; q++) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++) H[q][k] = t6_shift(H[q][k], T4_NEG + 1, sb, in);
-                        Ga[q] = (uint32_t)t6_shift((int)Ga[q], 0, sb, in);
-                        Gb[q] = (uint32_t)t6_shift((int)Gb[q], 0, sb, in);
+                        for (int k = 0; k < 4; k++) move(H[0][q][k], H[1][q][k], T4_NEG + 1);
+                        int x, y;
+                        x = (int)Ga[0][q]; y = (int)Ga[1][q]; move(x, y, 0); Ga[0][q] = (uint32_t)x; Ga[1][q] = (uint32_t)y;
+                        x = (int)Gb[0][q]; y = (int)Gb[1][q]; move(x, y, 0); Gb[0][q] = (uint32_t)x; Gb[1][q] = (uint32_t)y;
                     }
                 }
                 have_codes = false;
@@ -282,49 +325,12 @@ __global__ __launch_bounds__(64) void k_poa_dp_t6(const poa_prob *__restrict__ p
         } else if (r > 0) {
             // ---- STAGING (k_poa_dp_t5's, into registers): the virtual predecessor row of the predecessors' value rows
             have_codes = false;
-            if (np == 1) {
-                const int bp = __builtin_amdgcn_readfirstlane(R[ps].beg), ep = __builtin_amdgcn_readfirstlane(R[ps].end);
-                const uint8_t *Vq = (const uint8_t *)poa_uniform_u64(R[ps].voff);
-                const int balq = bp & ~3;
-                const int Wq = (ep - balq + 1 + 3) & ~3;
-                const unsigned pspan = (unsigned)(ep - bp);
-#pragma unroll
-                for (int q = 0; q < Q; q++) {
-                    const int j0 = jl + 4 * q;
-                    const int idx = j0 - balq;
-                    int4 hv = make_int4(T4_NEG + 1, T4_NEG + 1, T4_NEG + 1, T4_NEG + 1);
-                    uint2 gg = make_uint2(0u, 0u);
-                    if (idx >= 0 && idx < Wq) {
-                        hv = *(const int4 *)((const int32_t *)Vq + idx);
-                        gg = *(const uint2 *)(Vq + 4ll * Wq + 2ll * idx);
-                    }
-                    const bool in0 = (unsigned)(j0 - bp) <= pspan, in1 = (unsigned)(j0 + 1 - bp) <= pspan, in2 = (unsigned)(j0 + 2 - bp) <= pspan,
-                               in3 = (unsigned)(j0 + 3 - bp) <= pspan;
-                    H[q][0] = in0 ? hv.x : T4_NEG + 1; H[q][1] = in1 ? hv.y : T4_NEG + 1; H[q][2] = in2 ? hv.z : T4_NEG + 1; H[q][3] = in3 ? hv.w : T4_NEG + 1;
-                    Ga[q] = (in0 ? gg.x & 0xffffu : 0u) | (in1 ? gg.x & 0xffff0000u : 0u);
-                    Gb[q] = (in2 ? gg.y & 0xffffu : 0u) | (in3 ? gg.y & 0xffff0000u : 0u);
-                }
-                {
-                    const int idx = jl - 1 - balq;
-                    int wl = (idx >= 0 && idx < Wq) ? ((const int32_t *)Vq)[idx] : T4_NEG + 1;
-                    hp0 = (unsigned)(jl - 1 - bp) <= pspan ? wl : T4_NEG + 1;
-                }
-            } else {
-                int hm[Q][4], x1[Q][4], x2[Q][4];
-                uint32_t ah[Q], a1[Q], a2[Q];  // which predecessor won: a byte per cell (planes of the direction row)
-                int hl = T4_NEG + 1;
-                uint32_t ahl = 0;
-#pragma unroll
-                for (int q = 0; q < Q; q++) {
-                    ah[q] = 0; a1[q] = 0; a2[q] = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) { hm[q][k] = T4_NEG; x1[q][k] = T4_NEG; x2[q][k] = T4_NEG; }
-                }
-                hl = T4_NEG;
-                for (int t = 0; t < np; t++) {
-                    const uint32_t p = plist[ps + t];
-                    const int bp = __builtin_amdgcn_readfirstlane(R[p].beg), ep = __builtin_amdgcn_readfirstlane(R[p].end);
-                    const uint8_t *Vq = (const uint8_t *)poa_uniform_u64(R[p].voff);
+            auto stage = [&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                const int jl = nbase + CPL * (lane + 64 * s);
+                if (np == 1) {
+                    const int bp = __builtin_amdgcn_readfirstlane(R[ps].beg), ep = __builtin_amdgcn_readfirstlane(R[ps].end);
+                    const uint8_t *Vq = (const uint8_t *)poa_uniform_u64(R[ps].voff);
                     const int balq = bp & ~3;
                     const int Wq = (ep - balq + 1 + 3) & ~3;
                     const unsigned pspan = (unsigned)(ep - bp);
@@ -332,211 +338,299 @@ __global__ __launch_bounds__(64) void k_poa_dp_t6(const poa_prob *__restrict__ p
                     for (int q = 0; q < Q; q++) {
                         const int j0 = jl + 4 * q;
                         const int idx = j0 - balq;
-                        int4 hv = make_int4(0, 0, 0, 0);
+                        int4 hv = make_int4(T4_NEG + 1, T4_NEG + 1, T4_NEG + 1, T4_NEG + 1);
                         uint2 gg = make_uint2(0u, 0u);
                         if (idx >= 0 && idx < Wq) {
                             hv = *(const int4 *)((const int32_t *)Vq + idx);
                             gg = *(const uint2 *)(Vq + 4ll * Wq + 2ll * idx);
                         }
-                        const int hj[4] = {hv.x, hv.y, hv.z, hv.w};
-                        const uint32_t g16[4] = {gg.x & 0xffffu, gg.x >> 16, gg.y & 0xffffu, gg.y >> 16};
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            if ((unsigned)(j0 + k - bp) <= pspan) {
-                                const int h = hj[k], c1 = h - (int)(g16[k] & 255u), c2 = h - (int)(g16[k] >> 8);
-                                if (h > hm[q][k]) { hm[q][k] = h; ah[q] = (ah[q] & ~(255u << (8 * k))) | ((uint32_t)t << (8 * k)); }
-                                if (c1 > x1[q][k]) { x1[q][k] = c1; a1[q] = (a1[q] & ~(255u << (8 * k))) | ((uint32_t)t << (8 * k)); }
-                                if (c2 > x2[q][k]) { x2[q][k] = c2; a2[q] = (a2[q] & ~(255u << (8 * k))) | ((uint32_t)t << (8 * k)); }
-                            }
-                        }
+                        const bool in0 = (unsigned)(j0 - bp) <= pspan, in1 = (unsigned)(j0 + 1 - bp) <= pspan, in2 = (unsigned)(j0 + 2 - bp) <= pspan,
+                                   in3 = (unsigned)(j0 + 3 - bp) <= pspan;
+                        H[s][q][0] = in0 ? hv.x : T4_NEG + 1; H[s][q][1] = in1 ? hv.y : T4_NEG + 1; H[s][q][2] = in2 ? hv.z : T4_NEG + 1; H[s][q][3] = in3 ? hv.w : T4_NEG + 1;
+                        Ga[s][q] = (in0 ? gg.x & 0xffffu : 0u) | (in1 ? gg.x & 0xffff0000u : 0u);
+                        Gb[s][q] = (in2 ? gg.y & 0xffffu : 0u) | (in3 ? gg.y & 0xffff0000u : 0u);
                     }
                     {
                         const int idx = jl - 1 - balq;
-                        const int wl = (idx >= 0 && idx < Wq) ? ((const int32_t *)Vq)[idx] : 0;
-                        if (jl >= 1 && (unsigned)(jl - 1 - bp) <= pspan && wl > hl) { hl = wl; ahl = (uint32_t)t; }
+                        const int wl = (idx >= 0 && idx < Wq) ? ((const int32_t *)Vq)[idx] : T4_NEG + 1;
+                        hp0[s] = (unsigned)(jl - 1 - bp) <= pspan ? wl : T4_NEG + 1;
                     }
-                }
+                } else {
+                    int hm[Q][4], x1[Q][4], x2[Q][4];
+                    uint32_t ah[Q], a1[Q], a2[Q];  // which predecessor won: a byte per cell (planes of the direction row)
+                    int hl = T4_NEG;
+                    uint32_t ahl = 0;
 #pragma unroll
-                for (int q = 0; q < Q; q++) {
-                    uint32_t gv[4];
+                    for (int q = 0; q < Q; q++) {
+                        ah[q] = 0; a1[q] = 0; a2[q] = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        H[q][k] = hm[q][k];
-                        gv[k] = (uint32_t)(hm[q][k] - x1[q][k]) | ((uint32_t)(hm[q][k] - x2[q][k]) << 8);
+                        for (int k = 0; k < 4; k++) { hm[q][k] = T4_NEG; x1[q][k] = T4_NEG; x2[q][k] = T4_NEG; }
                     }
-                    Ga[q] = gv[0] | (gv[1] << 16);
-                    Gb[q] = gv[2] | (gv[3] << 16);
-                    // predecessor-choice planes: M of column j looks at column j - 1 of the predecessors
-                    const int c = jl + 4 * q - bal;
-                    if (c >= 0 && c < W) {
-                        const uint32_t left = q == 0 ? ahl : (ah[q > 0 ? q - 1 : 0] >> 24);
-                        *(uint32_t *)(drow + (uint32_t)(W + c)) = left | (ah[q] << 8);
-                        *(uint32_t *)(drow + (uint32_t)(2 * W + c)) = a1[q];
-                        *(uint32_t *)(drow + (uint32_t)(3 * W + c)) = a2[q];
+                    for (int t = 0; t < np; t++) {
+                        const uint32_t p = plist[ps + t];
+                        const int bp = __builtin_amdgcn_readfirstlane(R[p].beg), ep = __builtin_amdgcn_readfirstlane(R[p].end);
+                        const uint8_t *Vq = (const uint8_t *)poa_uniform_u64(R[p].voff);
+                        const int balq = bp & ~3;
+                        const int Wq = (ep - balq + 1 + 3) & ~3;
+                        const unsigned pspan = (unsigned)(ep - bp);
+#pragma unroll
+                        for (int q = 0; q < Q; q++) {
+                            const int j0 = jl + 4 * q;
+                            const int idx = j0 - balq;
+                            int4 hv = make_int4(0, 0, 0, 0);
+                            uint2 gg = make_uint2(0u, 0u);
+                            if (idx >= 0 && idx < Wq) {
+                                hv = *(const int4 *)((const int32_t *)Vq + idx);
+                                gg = *(const uint2 *)(Vq + 4ll * Wq + 2ll * idx);
+                            }
+                            const int hj[4] = {hv.x, hv.y, hv.z, hv.w};
+                            const uint32_t g16[4] = {gg.x & 0xffffu, gg.x >> 16, gg.y & 0xffffu, gg.y >> 16};
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if ((unsigned)(j0 + k - bp) <= pspan) {
+                                    const int h = hj[k], c1 = h - (int)(g16[k] & 255u), c2 = h - (int)(g16[k] >> 8);
+                                    if (h > hm[q][k]) { hm[q][k] = h; ah[q] = (ah[q] & ~(255u << (8 * k))) | ((uint32_t)t << (8 * k)); }
+                                    if (c1 > x1[q][k]) { x1[q][k] = c1; a1[q] = (a1[q] & ~(255u << (8 * k))) | ((uint32_t)t << (8 * k)); }
+                                    if (c2 > x2[q][k]) { x2[q][k] = c2; a2[q] = (a2[q] & ~(255u << (8 * k))) | ((uint32_t)t << (8 * k)); }
+                                }
+                            }
+                        }
+                        {
+                            const int idx = jl - 1 - balq;
+                            const int wl = (idx >= 0 && idx < Wq) ? ((const int32_t *)Vq)[idx] : 0;
+                            if (jl >= 1 && (unsigned)(jl - 1 - bp) <= pspan && wl > hl) { hl = wl; ahl = (uint32_t)t; }
+                        }
                     }
+#pragma unroll
+                    for (int q = 0; q < Q; q++) {
+                        uint32_t gv[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            H[s][q][k] = hm[q][k];
+                            gv[k] = (uint32_t)(hm[q][k] - x1[q][k]) | ((uint32_t)(hm[q][k] - x2[q][k]) << 8);
+                        }
+                        Ga[s][q] = gv[0] | (gv[1] << 16);
+                        Gb[s][q] = gv[2] | (gv[3] << 16);
+                        // predecessor-choice planes: M of column j looks at column j - 1 of the predecessors
+                        const int c = jl + 4 * q - bal;
+                        if (c >= 0 && c < W) {
+                            const uint32_t left = q == 0 ? ahl : (ah[q > 0 ? q - 1 : 0] >> 24);
+                            *(uint32_t *)(drow + (uint32_t)(W + c)) = left | (ah[q] << 8);
+                            *(uint32_t *)(drow + (uint32_t)(2 * W + c)) = a1[q];
+                            *(uint32_t *)(drow + (uint32_t)(3 * W + c)) = a2[q];
+                        }
+                    }
+                    hp0[s] = hl;
                 }
-                hp0 = hl;
-            }
+            };
+            stage(std::integral_constant<int, 0>{});
+            if (two) stage(std::integral_constant<int, 1>{});
         }
         wbase = nbase;
         if (!have_codes) {
-            // (jl is a multiple of 4: the quads' halfwords are adjacent)
+            // (a lane's first column is a multiple of 4: the quads' halfwords are adjacent)
 #pragma unroll
-            for (int q = 0; q < Q; q++) {
-                const int t = (jl >> 2) + q;
-                qn[q] = t < (int)(lds_cols / 4) ? (uint32_t)Qn[t] : 0u;
-            }
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const int t = ((nbase + CPL * (lane + 64 * s)) >> 2) + q;
+                    qn[s][q] = t < (int)(lds_cols / 4) ? (uint32_t)Qn[t] : 0u;
+                }
             have_codes = true;
         }
 
-        POA_MARK("t6_p1");
-        // ---- phase 1: M / E1 / E2 from the row above, Ht' (tagged); the lane's part of the max-plus scan
-        int agg1, agg2, alast1, alast2;
-        if (__builtin_expect(r > 0, 1)) {
-            int hp = hp0;
+        // right of `end` the row is cleaned on the way out: virtual lanes above le, and in lane le the cells above se
+        const int le = (end - nbase) / CPL, se = (end - nbase) - le * CPL;
+        const int sb = beg - nbase;  // 0 .. CPL - 1: cells of the first lane left of beg stay out of the scan
+        int bestv[2] = {INT32_MIN, INT32_MIN};
+        int tot1 = POA_IDENT, tot2 = POA_IDENT, lst1 = POA_IDENT, lst2 = POA_IDENT;  // what a step hands to the next one
+        auto step = [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            const int jl = nbase + CPL * (lane + 64 * s);
+            const int le1 = lane_e1 + 4 * e1 * WIN * s, le2 = lane_e2 + 4 * e2 * WIN * s;
+            int htt[Q][4], ht4[Q][4], e1t[Q][4], e2t[Q][4];
+            POA_MARK("t6_p1");
+            // ---- phase 1: M / E1 / E2 from the row above, Ht' (tagged); the lane's part of the max-plus scan
+            if (__builtin_expect(r > 0, 1)) {
+                int hp = hp0[s];
+#pragma unroll
+                for (int q = 0; q < Q; q++) {
+                    const uint32_t eqb = qn[s][q] >> gsh;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int g = (int)(k < 2 ? Ga[s][q] : Gb[s][q]);
+                        const int ev1 = (k & 1) ? t4_sub_byte<2>(H[s][q][k], g) : t4_sub_byte<0>(H[s][q][k], g);
+                        const int ev2 = (k & 1) ? t4_sub_byte<3>(H[s][q][k], g) : t4_sub_byte<1>(H[s][q][k], g);
+                        const int m = (int)__umul24(__builtin_amdgcn_ubfe(eqb, 4u * k, 1u), (uint32_t)mm4) + (hp + ne4t);
+                        htt[q][k] = t4_max3(m, ev1, ev2);
+                        e1t[q][k] = ev1;
+                        e2t[q][k] = ev2;
+                        hp = H[s][q][k];
+                    }
+                }
+            } else {
+                // the source row: H(0, 0) = 0, everything else comes out of the insertion scan
+#pragma unroll
+                for (int q = 0; q < Q; q++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        htt[q][k] = (jl + 4 * q + k == 0 ? 0 : T4_NEG) + 2;
+                        e1t[q][k] = T4_NEG + 1;
+                        e2t[q][k] = T4_NEG;
+                    }
+            }
+            POA_MARK("t6_scan");
+            int agg1, agg2, alast1 = POA_IDENT, alast2 = POA_IDENT;
+            {
+                int a1 = POA_IDENT, a2 = POA_IDENT;
+#pragma unroll
+                for (int q = 0; q < Q; q++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int c = 4 * q + k;
+                        int h4 = htt[q][k] & ~3;
+                        // (cells left of beg: only the first lane has any, and never its last cell; their tags do not matter)
+                        if (s == 0 && c < CPL - 1) h4 = (lane == 0 && c < sb) ? POA_IDENT : h4;
+                        ht4[q][k] = h4;
+                        const int r1 = h4 + 4 * e1 * c, r2 = h4 + 4 * e2 * c;
+                        a1 = r1 > a1 ? r1 : a1;
+                        a2 = r2 > a2 ? r2 : a2;
+                        if (c == CPL - 1) { alast1 = r1 + le1; alast2 = r2 + le2; }
+                    }
+                agg1 = a1 + le1;
+                agg2 = a2 + le2;
+            }
+            const int i1 = poa_wave_scan_max(agg1), i2 = poa_wave_scan_max(agg2);
+            const int run1_ = t4_shr1_max(i1, tot1), run2_ = t4_shr1_max(i2, tot2);
+            const int la1_ = t4_shr1_mov(alast1, lst1), la2_ = t4_shr1_mov(alast2, lst2);
+            if (s == 0 && two) {
+                const int a = __builtin_amdgcn_readlane(i1, 63), b = __builtin_amdgcn_readlane(i2, 63);
+                tot1 = a; tot2 = b;
+                lst1 = __builtin_amdgcn_readlane(alast1, 63);
+                lst2 = __builtin_amdgcn_readlane(alast2, 63);
+            }
+            POA_MARK("t6_p2");
+            // ---- phase 2: H'' = max3(Ht, F1, F2), the cell words, gap bytes and direction dwords; the row maximum
+            int R1 = run1_ - le1, R2 = run2_ - le2, L1 = la1_ - le1, L2 = la2_ - le2;
+            int best = INT32_MIN;
+            uint32_t dirs[Q];
+            const int lg = lane + 64 * s;
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                const uint32_t eqb = qn[q] >> gsh;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int g = (int)(k < 2 ? Ga[q] : Gb[q]);
-                    const int ev1 = (k & 1) ? t4_sub_byte<2>(H[q][k], g) : t4_sub_byte<0>(H[q][k], g);
-                    const int ev2 = (k & 1) ? t4_sub_byte<3>(H[q][k], g) : t4_sub_byte<1>(H[q][k], g);
-                    const int m = (int)__umul24(__builtin_amdgcn_ubfe(eqb, 4u * k, 1u), (uint32_t)mm4) + (hp + ne4t);
-                    htt[q][k] = t4_max3(m, ev1, ev2);
-                    e1t[q][k] = ev1;
-                    e2t[q][k] = ev2;
-                    hp = H[q][k];
-                }
-            }
-        } else {
-            // the source row: H(0, 0) = 0, everything else comes out of the insertion scan
-#pragma unroll
-            for (int q = 0; q < Q; q++)
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    htt[q][k] = (jl + 4 * q + k == 0 ? 0 : T4_NEG) + 2;
-                    e1t[q][k] = T4_NEG + 1;
-                    e2t[q][k] = T4_NEG;
-                }
-        }
-        POA_MARK("t6_scan");
-        // cells left of beg (first lane only) stay out of the scan; their own words come out far below everything
-        const int sb = beg - nbase;  // 0 .. CPL - 1
-        {
-            int a1 = POA_IDENT, a2 = POA_IDENT;
-#pragma unroll
-            for (int q = 0; q < Q; q++)
+                int dirq = 0, ga = 0, gbb = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int c = 4 * q + k;
-                    int h4 = htt[q][k] & ~3;
-                    if (c < CPL - 1) h4 = (lane == 0 && c < sb) ? POA_IDENT : h4;  // (c = CPL - 1 is never left of beg)
-                    htt[q][k] = h4 | (htt[q][k] & 3);
-                    const int r1 = h4 + 4 * e1 * c, r2 = h4 + 4 * e2 * c;
-                    a1 = r1 > a1 ? r1 : a1;
-                    a2 = r2 > a2 ? r2 : a2;
-                    if (c == CPL - 1) { alast1 = r1 + lane_e1; alast2 = r2 + lane_e2; }
+                    const int h4 = ht4[q][k];
+                    const int f1 = R1 - (4 * (o1 + e1 * c) - 1), f2 = R2 - 4 * (o2 + e2 * c);
+                    const int hh = t4_max3(h4 | 3, f1, f2);
+                    const int h = (hh & ~3) | 1;
+                    int acc = (hh << 2) | (htt[q][k] & 3);
+                    const int u1 = h - e1t[q][k], u2 = h - e2t[q][k];
+                    if (k == 0) { t5_min_byte<0>(ga, u1, D1); t5_min_byte<1>(ga, u2, D2); }
+                    if (k == 1) { t5_min_byte<2>(ga, u1, D1); t5_min_byte<3>(ga, u2, D2); }
+                    if (k == 2) { t5_min_byte<0>(gbb, u1, D1); t5_min_byte<1>(gbb, u2, D2); }
+                    if (k == 3) { t5_min_byte<2>(gbb, u1, D1); t5_min_byte<3>(gbb, u2, D2); }
+                    t4_flag_ne(acc, R1, L1);
+                    if (k == 0) t4_flag_ne_dep<0>(dirq, acc, R2, L2);
+                    if (k == 1) t4_flag_ne_dep<1>(dirq, acc, R2, L2);
+                    if (k == 2) t4_flag_ne_dep<2>(dirq, acc, R2, L2);
+                    if (k == 3) t4_flag_ne_dep<3>(dirq, acc, R2, L2);
+                    L1 = h4 + 4 * e1 * c; L2 = h4 + 4 * e2 * c;
+                    R1 = L1 > R1 ? L1 : R1;
+                    R2 = L2 > R2 ? L2 : R2;
+                    // clean on the way out
+                    const bool off = lg > le || (lg == le && c > se);
+                    H[s][q][k] = off ? T4_NEG + 1 : h;
                 }
-            agg1 = a1 + lane_e1;
-            agg2 = a2 + lane_e2;
-        }
-        const int i1 = poa_wave_scan_max(agg1), i2 = poa_wave_scan_max(agg2);
-        const int run1_ = t4_shr1_max(i1, POA_IDENT), run2_ = t4_shr1_max(i2, POA_IDENT);
-        const int la1_ = t4_shr1_mov(alast1, POA_IDENT), la2_ = t4_shr1_mov(alast2, POA_IDENT);
-
-        POA_MARK("t6_p2");
-        // ---- phase 2: H'' = max3(Ht, F1, F2), the cell words, gap bytes and direction dwords; the row maximum
-        // right of `end` the row is cleaned on the way out: lanes above le, and in lane le the cells above se
-        const int le = (end - nbase) / CPL, se = (end - nbase) - le * CPL;
-        int R1 = run1_ - lane_e1, R2 = run2_ - lane_e2, L1 = la1_ - lane_e1, L2 = la2_ - lane_e2;
-        int best = INT32_MIN;
-        uint32_t dirs[Q];
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            int dirq = 0, ga = 0, gbb = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int c = 4 * q + k;
-                const int h4 = htt[q][k] & ~3;
-                const int f1 = R1 - (4 * (o1 + e1 * c) - 1), f2 = R2 - 4 * (o2 + e2 * c);
-                const int hh = t4_max3(h4 | 3, f1, f2);
-                const int h = (hh & ~3) | 1;
-                int acc = (hh << 2) | (htt[q][k] & 3);
-                const int u1 = h - e1t[q][k], u2 = h - e2t[q][k];
-                if (k == 0) { t5_min_byte<0>(ga, u1, D1); t5_min_byte<1>(ga, u2, D2); }
-                if (k == 1) { t5_min_byte<2>(ga, u1, D1); t5_min_byte<3>(ga, u2, D2); }
-                if (k == 2) { t5_min_byte<0>(gbb, u1, D1); t5_min_byte<1>(gbb, u2, D2); }
-                if (k == 3) { t5_min_byte<2>(gbb, u1, D1); t5_min_byte<3>(gbb, u2, D2); }
-                t4_flag_ne(acc, R1, L1);
-                if (k == 0) t4_flag_ne_dep<0>(dirq, acc, R2, L2);
-                if (k == 1) t4_flag_ne_dep<1>(dirq, acc, R2, L2);
-                if (k == 2) t4_flag_ne_dep<2>(dirq, acc, R2, L2);
-                if (k == 3) t4_flag_ne_dep<3>(dirq, acc, R2, L2);
-                L1 = h4 + 4 * e1 * c; L2 = h4 + 4 * e2 * c;
-                R1 = L1 > R1 ? L1 : R1;
-                R2 = L2 > R2 ? L2 : R2;
-                // clean on the way out
-                const bool off = lane > le || (lane == le && c > se);
-                H[q][k] = off ? T4_NEG + 1 : h;
+                {
+                    const uint32_t ya = (uint32_t)ga + e_probe, yb = ((uint32_t)gbb + e_probe) >> 1;
+                    const uint32_t e8 = (ya & 0x80808080u) | (yb & ~0x80808080u);
+                    dirq = (int)((e8 & 0xC0C0C0C0u) | ((uint32_t)dirq & ~0xC0C0C0C0u));
+                    Ga[s][q] = (uint32_t)ga + g_bias;
+                    Gb[s][q] = (uint32_t)gbb + g_bias;
+                }
+                dirs[q] = (uint32_t)dirq;
+                const int m3 = t4_max3(H[s][q][0], H[s][q][1], H[s][q][2]);
+                const int m4 = m3 > H[s][q][3] ? m3 : H[s][q][3];
+                best = m4 > best ? m4 : best;
             }
-            {
-                const uint32_t ya = (uint32_t)ga + e_probe, yb = ((uint32_t)gbb + e_probe) >> 1;
-                const uint32_t e8 = (ya & 0x80808080u) | (yb & ~0x80808080u);
-                dirq = (int)((e8 & 0xC0C0C0C0u) | ((uint32_t)dirq & ~0xC0C0C0C0u));
-                Ga[q] = (uint32_t)ga + g_bias;
-                Gb[q] = (uint32_t)gbb + g_bias;
-            }
-            dirs[q] = (uint32_t)dirq;
-            const int m3 = t4_max3(H[q][0], H[q][1], H[q][2]);
-            const int m4 = m3 > H[q][3] ? m3 : H[q][3];
-            best = m4 > best ? m4 : best;
-        }
-        POA_MARK("t6_stores");
-        // ---- stores: direction dwords, and the value row of a node's last base (what a far successor reads)
+            bestv[s] = best;
+            POA_MARK("t6_stores");
+            // ---- stores: direction dwords, and the value row of a node's last base (what a far successor reads)
 #pragma unroll
-        for (int q = 0; q < Q; q++) {
-            const int c = jl + 4 * q - bal;
-            if (c >= 0 && c < W) {
-                *(uint32_t *)(drow + (uint32_t)c) = dirs[q];
-                if (last) {
-                    *(int4 *)(Vrow + 4u * (uint32_t)c) = make_int4(H[q][0], H[q][1], H[q][2], H[q][3]);
-                    *(uint2 *)(Vrow + (uint32_t)(4 * W + 2 * c)) = make_uint2(Ga[q], Gb[q]);
+            for (int q = 0; q < Q; q++) {
+                const int c = jl + 4 * q - bal;
+                if (c >= 0 && c < W) {
+                    *(uint32_t *)(drow + (uint32_t)c) = dirs[q];
+                    if (last) {
+                        *(int4 *)(Vrow + 4u * (uint32_t)c) = make_int4(H[s][q][0], H[s][q][1], H[s][q][2], H[s][q][3]);
+                        *(uint2 *)(Vrow + (uint32_t)(4 * W + 2 * c)) = make_uint2(Ga[s][q], Gb[s][q]);
+                    }
                 }
             }
-        }
+        };
+        step(std::integral_constant<int, 0>{});
+        if (__builtin_expect(two, 0)) step(std::integral_constant<int, 1>{});
+        b_live = two;
         POA_MARK("t6_rowmax");
         // ---- the row maximum and its leftmost / rightmost column (cells outside the band are far below it)
         {
-            const int wb = __builtin_amdgcn_readlane(poa_wave_scan_max(best), 63);
-            const uint64_t holders = __builtin_amdgcn_ballot_w64(best == wb);
-            const int lf = __builtin_ctzll(holders), lr = 63 - __builtin_clzll(holders);
-            int cf = 0, cr = 0;
+            const int wb0 = __builtin_amdgcn_readlane(poa_wave_scan_max(bestv[0]), 63);
+            int wb = wb0, wb1 = INT32_MIN;
+            if (two) { wb1 = __builtin_amdgcn_readlane(poa_wave_scan_max(bestv[1]), 63); wb = wb1 > wb ? wb1 : wb; }
+            // one compare per slot gives the holders of the maximum as a lane mask per slot: the first / last holding lane of any slot,
+            // then the first / last slot of that lane, are scalar bit tests
+            auto first_of = [&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                uint64_t m[CPL], any = 0;
 #pragma unroll
-            for (int q = Q - 1; q >= 0; q--)
+                for (int q = 0; q < Q; q++)
 #pragma unroll
-                for (int k = 3; k >= 0; k--)
-                    if (__builtin_amdgcn_readlane(H[q][k], lf) == wb) cf = 4 * q + k;
+                    for (int k = 0; k < 4; k++) { m[4 * q + k] = __builtin_amdgcn_ballot_w64(H[s][q][k] == wb); any |= m[4 * q + k]; }
+                const int lf = __builtin_ctzll(any);
+                int cf = 0;
 #pragma unroll
-            for (int q = 0; q < Q; q++)
+                for (int c = CPL - 1; c >= 0; c--)
+                    if ((m[c] >> lf) & 1ull) cf = c;
+                return nbase + CPL * (lf + 64 * s) + cf;
+            };
+            auto last_of = [&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                uint64_t m[CPL], any = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (__builtin_amdgcn_readlane(H[q][k], lr) == wb) cr = 4 * q + k;
-            prev_lmax = nbase + CPL * lf + cf;
-            prev_rmax = nbase + CPL * lr + cr;
+                for (int q = 0; q < Q; q++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) { m[4 * q + k] = __builtin_amdgcn_ballot_w64(H[s][q][k] == wb); any |= m[4 * q + k]; }
+                const int lr = 63 - __builtin_clzll(any);
+                int cr = 0;
+#pragma unroll
+                for (int c = 0; c < CPL; c++)
+                    if ((m[c] >> lr) & 1ull) cr = c;
+                return nbase + CPL * (lr + 64 * s) + cr;
+            };
+            if (__builtin_expect(!two, 1)) {
+                prev_lmax = first_of(std::integral_constant<int, 0>{});
+                prev_rmax = last_of(std::integral_constant<int, 0>{});
+            } else {
+                prev_lmax = wb0 == wb ? first_of(std::integral_constant<int, 0>{}) : first_of(std::integral_constant<int, 1>{});
+                prev_rmax = wb1 == wb ? last_of(std::integral_constant<int, 1>{}) : last_of(std::integral_constant<int, 0>{});
+            }
             if (last && lane == 0) { R[r].lmax = prev_lmax; R[r].rmax = prev_rmax; }
         }
         POA_MARK("t6_sink");
         if (__builtin_expect(is_sink, 0)) {
             int val = POA_NEG;
             if (qlen >= beg && qlen <= end) {
-                const int ls = (qlen - nbase) / CPL, cs = (qlen - nbase) - ls * CPL;
+                const int lq = (qlen - nbase) / CPL, cs = (qlen - nbase) - lq * CPL;
                 int w = 0;
 #pragma unroll
-                for (int q = 0; q < Q; q++)
+                for (int s = 0; s < 2; s++)
 #pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (cs == 4 * q + k) w = __builtin_amdgcn_readlane(H[q][k], ls);
+                    for (int q = 0; q < Q; q++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (cs == 4 * q + k && (lq >> 6) == s) w = __builtin_amdgcn_readlane(H[s][q][k], lq & 63);
                 val = w >> 2;
             }
             if (sink_row1 == 0 || val > sink_val) { sink_val = val; sink_row1 = r + 1; }

@@ -123,8 +123,10 @@ struct MapOptions {
     std::vector<int> devices;            // empty: `device` alone (--devices all: every visible GPU)
     bool all_devices = false;
     uint64_t chunk_reads = 32768;
-    // the caller is about to leave the process: the contexts are not torn down (freeing tens of GB of HBM takes the driver
-    // hundreds of milliseconds that a command line tool would only spend waiting)
+    // the caller is about to leave the process with _exit: the contexts are not torn down (freeing tens of GB of HBM takes the
+    // driver hundreds of milliseconds that a command line tool would only spend waiting), tear-down threads may still be running
+    // when map_reads_multi returns.  ONLY for callers that leave the process right after a successful return (the contexts leak
+    // otherwise); when anything fails, map_reads_multi joins those threads and destroys every context before it throws.
     bool leave_contexts = false;
     // false: map_reads_multi writes the GAF files chunk by chunk and returns no text (the CLI without -C / -v); true: the
     // whole GAF text comes back in MapOutput
@@ -152,6 +154,10 @@ struct Shard {
 // at most chunk_reads reads.  Shards come in read order; concatenating their outputs reproduces the single-batch output.
 std::vector<Shard> plan_shards(const std::vector<uint64_t> &read_lengths, uint32_t n_slots, uint64_t chunk_reads);
 
+// diagnostics: the text half of the product path replayed (vgh_map.cpp: textpath_replay)
+struct TextReplay { uint64_t bytes = 0, chains_bytes = 0; double seconds = 0, text_seconds = 0, write_seconds = 0; unsigned threads = 0; };
+TextReplay textpath_replay(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt, const std::string &out_prefix,
+                           unsigned repeat, unsigned n_threads);
 // ctx must already hold the uploaded index: maps everything on that one context, in chunks of opt.chunk_reads.
 // out_prefix == "" writes no files.
 MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt,

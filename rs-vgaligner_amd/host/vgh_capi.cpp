@@ -170,5 +170,21 @@ int vgh_map_reads_multi(void *h, uint64_t n, const char *const *names, const cha
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 
+// diagnostics (tests/prof_textpath.py): GAF text + file appends of one chunk, repeated; out[0..5] = bytes, chains bytes, seconds,
+// seconds in text, seconds in appends, threads
+int vgh_textpath_replay(vga_ctx *ctx, void *h, uint64_t n, const char *const *names, const char *const *seqs, const char *out_prefix, uint32_t repeat,
+                        uint32_t n_threads, double *out)
+{
+    try {
+        std::vector<QuerySequence> in(n);
+        for (uint64_t i = 0; i < n; i++) in[i] = {names[i], seqs[i]};
+        MapOptions opt;
+        opt.also_align = true;
+        const TextReplay r = textpath_replay(ctx, ((IndexBox *)h)->ix, in, opt, out_prefix, repeat, n_threads);
+        out[0] = (double)r.bytes; out[1] = (double)r.chains_bytes; out[2] = r.seconds; out[3] = r.text_seconds; out[4] = r.write_seconds; out[5] = r.threads;
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
+
 void vgh_free(void *p) { free(p); }
 }

@@ -21,6 +21,11 @@
 #include <thread>
 #include <type_traits>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 namespace vgh {
 
 void trace_mark(const char *what)
@@ -321,12 +326,93 @@ void append_pieces(std::string &dst, std::vector<std::string> &pieces)
     for (auto &q : pieces) { dst += q; std::string().swap(q); }
 }
 
-unsigned text_threads()
+// host threads that put GAF text together (and copy it into the files) for one context: the cores of the host shared between the
+// device slots -- 8 ranks on one host must not each start 32 threads -- with VGA_HOST_THREADS as the diagnostic override
+unsigned text_threads(uint32_t n_slots)
 {
-    // (the heavy part of the GAF text -- the chains' path column -- comes from the GPU; what is left is copying)
     if (const char *e = getenv("VGA_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
-    return std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return std::max(2u, std::min(32u, hw / std::max(1u, n_slots)));
 }
+
+// A GAF file that grows by whole chunks whose text already exists in pieces: the file is extended and the pieces are written at
+// their offsets (known once a chunk's text exists: the order is fixed by the plan) by several threads at once, in slices of
+// 8 MiB -- pwrite by default; VGA_GAF_MMAP=1 copies into a shared mapping of the new range instead.  Measured on the GPU box
+// (overlay file system, tests/prof_textpath.py, config 5, 973 MB per round): one writer thread 1.1 GB/s (round 3), the mapping
+// 1.6-1.7 GB/s whatever the number of threads (page faults), pwrite from 16 threads 4.5 GB/s.
+class AppendFile {
+public:
+    explicit AppendFile(const std::string &path) : path_(path)
+    {
+        fd_ = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+        if (fd_ < 0) throw Error("Couldn't create file " + path);
+    }
+    ~AppendFile() { if (fd_ >= 0) ::close(fd_); }
+    AppendFile(const AppendFile &) = delete;
+    AppendFile &operator=(const AppendFile &) = delete;
+    uint64_t size() const { return size_; }
+    // appends the pieces in order (and frees them); up to n_threads copy
+    void append(std::vector<std::string> &pieces, unsigned n_threads)
+    {
+        uint64_t total = 0;
+        for (const std::string &q : pieces) total += q.size();
+        if (total == 0) { pieces.clear(); return; }
+        const uint64_t old = size_;
+        if (::ftruncate(fd_, (off_t)(old + total)) != 0) throw Error("Couldn't write to file " + path_);
+        // slices of at most 8 MiB, dealt to the threads round robin
+        struct Slice { const char *src; uint64_t off, len; };
+        std::vector<Slice> slices;
+        {
+            uint64_t off = old;
+            for (const std::string &q : pieces) {
+                for (uint64_t a = 0; a < q.size(); a += (8u << 20)) {
+                    const uint64_t len = std::min<uint64_t>(8u << 20, q.size() - a);
+                    slices.push_back({q.data() + a, off + a, len});
+                }
+                off += q.size();
+            }
+        }
+        const long page = sysconf(_SC_PAGESIZE);
+        const uint64_t map_off = old & ~((uint64_t)page - 1);
+        const size_t map_len = (size_t)(old + total - map_off);
+        char *base = use_mmap_ ? (char *)::mmap(nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, (off_t)map_off) : (char *)MAP_FAILED;
+        if (base == (char *)MAP_FAILED) use_mmap_ = false;
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(n_threads, slices.size()));
+        std::vector<std::string> errs(T);
+        auto work = [&](unsigned t) {
+            for (size_t i = t; i < slices.size(); i += T) {
+                const Slice &sl = slices[i];
+                if (use_mmap_) memcpy(base + (sl.off - map_off), sl.src, sl.len);
+                else {
+                    uint64_t done = 0;
+                    while (done < sl.len) {
+                        const ssize_t w = ::pwrite(fd_, sl.src + done, sl.len - done, (off_t)(sl.off + done));
+                        if (w <= 0) { errs[t] = "Couldn't write to file " + path_; return; }
+                        done += (uint64_t)w;
+                    }
+                }
+            }
+        };
+        if (T == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < T; t++) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+        if (use_mmap_) ::munmap(base, map_len);
+        for (const std::string &e : errs)
+            if (!e.empty()) throw Error(e);
+        size_ = old + total;
+        for (std::string &q : pieces) std::string().swap(q);
+        pieces.clear();
+    }
+
+private:
+    std::string path_;
+    int fd_ = -1;
+    uint64_t size_ = 0;
+    bool use_mmap_ = getenv("VGA_GAF_MMAP") != nullptr;
+};
 
 struct ChunkOut {
     std::vector<std::string> chains, aligns;  // GAF text in read order, in pieces
@@ -342,7 +428,7 @@ struct ChunkHooks {
 
 // anchors -> chains -> (alignments) of reads [b, e) on one context; the GAF text of exactly those reads
 void map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, uint64_t b0, uint64_t e0, const MapOptions &opt, ChunkOut &out,
-               const ChunkHooks &hooks)
+               const ChunkHooks &hooks, unsigned T)
 {
     const uint64_t n = e0 - b0;
     const bool trace = getenv("VGA_TRACE") != nullptr;
@@ -386,7 +472,6 @@ void map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &
     // chains GAF (map.rs:123-145): every chain of every read, in order.  The path column of every chain is written by the GPU
     // (K6) and the records are put together around it, on a thread beside the alignment call: K6 works on a stream of its own
     // (include/vga_hip.h) and the rest only reads the chains
-    const unsigned T = text_threads();
     std::string chain_err;
     std::mutex k6_mu;
     std::condition_variable k6_cv;
@@ -461,6 +546,88 @@ void map_chunk(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &
     if (!chain_err.empty()) throw Error(chain_err);
 }
 
+}  // namespace
+
+// Diagnostics (tests/prof_textpath.py): the text half of the product path on its own.  One chunk is mapped and aligned once; then,
+// `repeat` times, its GAF text is put together (chains and alignments side by side, as in map_chunk) and appended to two files
+// (AppendFile), and the rate of GAF bytes is what comes back.  Nothing of this is on the path of map_reads / map_reads_multi.
+TextReplay textpath_replay(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequence> &inputs, const MapOptions &opt, const std::string &out_prefix,
+                           unsigned repeat, unsigned n_threads)
+{
+    const uint64_t n = inputs.size();
+    std::string concat;
+    std::vector<uint64_t> off(n + 1, 0);
+    for (uint64_t i = 0; i < n; i++) { concat += inputs[i].seq; off[i + 1] = concat.size(); }
+    vga_batch *b = nullptr;
+    if (vga_batch_create(ctx, concat.data(), off.data(), n, &b) != VGA_OK) throw Error(vga_last_error(ctx));
+    std::unique_ptr<vga_batch, void (*)(vga_batch *)> b_owner(b, vga_batch_destroy);
+    vga_map_params mp;
+    vga_map_default_params(&mp);
+    mp.bandwidth = (uint32_t)opt.bandwidth; mp.max_gap = opt.max_gap; mp.chain_min_n_anchors = (uint32_t)opt.chain_min_n_anchors; mp.emit_dp = 0;
+    vga_map_result *m = nullptr;
+    if (vga_map_batch(b, &mp, &m) != VGA_OK) throw Error(vga_last_error(ctx));
+    std::unique_ptr<vga_map_result, void (*)(vga_map_result *)> m_owner(m, vga_map_result_free);
+    vga_chain_text *ct = nullptr;
+    if (vga_chain_paths_text(ctx, m, &ct) != VGA_OK) throw Error(vga_last_error(ctx));
+    std::unique_ptr<vga_chain_text, void (*)(vga_chain_text *)> ct_owner(ct, vga_chain_text_free);
+    vga_poa_params pp;
+    vga_poa_default_params(&pp);
+    vga_align_result *a = nullptr;
+    if (vga_align_batch(b, m, (uint32_t)opt.align_best_n, &pp, &a) != VGA_OK) throw Error(vga_last_error(ctx));
+    std::unique_ptr<vga_align_result, void (*)(vga_align_result *)> a_owner(a, vga_align_result_free);
+    const unsigned T = n_threads ? n_threads : text_threads(1);
+    TextReplay res;
+    AppendFile fc(out_prefix + "-chains.gaf"), fa(out_prefix + "-alignments.gaf");
+    const auto t0 = std::chrono::steady_clock::now();
+    double text_s = 0, write_s = 0;
+    for (unsigned k = 0; k < repeat; k++) {
+        std::string err[2];
+        double ts[2] = {0, 0}, ws[2] = {0, 0};
+        std::thread tc([&]() {
+            try {
+                const auto a0 = std::chrono::steady_clock::now();
+                std::vector<std::string> pieces = text_of_reads(n, std::max(1u, T / 2), [&](uint64_t r, std::string &dst) {
+                    for (uint64_t c = m->chain_off[r]; c < m->chain_off[r + 1]; c++)
+                        gaf_from_chain_text(dst, ix, inputs[r], m, r, c, ct->text + ct->text_off[c], ct->text_off[c + 1] - ct->text_off[c]);
+                }, [&](uint64_t r) {
+                    const uint64_t c0 = m->chain_off[r], c1 = m->chain_off[r + 1];
+                    return (size_t)(ct->text_off[c1] - ct->text_off[c0]) + (size_t)(c1 - c0) * (inputs[r].name.size() + 128);
+                });
+                const auto a1 = std::chrono::steady_clock::now();
+                fc.append(pieces, std::max(2u, T));
+                ts[0] = std::chrono::duration<double>(a1 - a0).count();
+                ws[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - a1).count();
+            } catch (const std::exception &e) { err[0] = e.what(); }
+        });
+        try {
+            const auto a0 = std::chrono::steady_clock::now();
+            std::vector<std::string> pieces = text_of_reads(n, T, [&](uint64_t r, std::string &dst) { gaf_from_alignment(dst, inputs[r], a, r); },
+                                                            [&](uint64_t r) {
+                                                                return (size_t)(a->cs_off[r + 1] - a->cs_off[r]) + (size_t)(a->cigar_off[r + 1] - a->cigar_off[r]) +
+                                                                       (size_t)(a->path_off[r + 1] - a->path_off[r]) * 8 + inputs[r].name.size() + 160;
+                                                            });
+            const auto a1 = std::chrono::steady_clock::now();
+            fa.append(pieces, std::max(2u, T));
+            ts[1] = std::chrono::duration<double>(a1 - a0).count();
+            ws[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - a1).count();
+        } catch (const std::exception &e) { err[1] = e.what(); }
+        tc.join();
+        for (const std::string &e : err)
+            if (!e.empty()) throw Error(e);
+        text_s += std::max(ts[0], ts[1]);
+        write_s += std::max(ws[0], ws[1]);
+    }
+    res.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    res.bytes = fc.size() + fa.size();
+    res.chains_bytes = fc.size();
+    res.text_seconds = text_s;
+    res.write_seconds = write_s;
+    res.threads = T;
+    return res;
+}
+
+namespace {
+
 void check_aligner(const MapOptions &opt)
 {
     if (opt.poa_aligner != "abpoa") {
@@ -501,7 +668,7 @@ MapOutput map_reads(vga_ctx *ctx, const Index &ix, const std::vector<QuerySequen
     for (size_t i = 0; i < inputs.size(); i++) len[i] = inputs[i].seq.size();
     for (const Shard &s : plan_shards(len, 1, opt.chunk_reads)) {
         ChunkOut c;
-        map_chunk(ctx, ix, inputs, s.begin, s.end, opt, c, ChunkHooks());
+        map_chunk(ctx, ix, inputs, s.begin, s.end, opt, c, ChunkHooks(), text_threads(1));
         append_pieces(out.chains_gaf, c.chains);
         append_pieces(out.alignments_gaf, c.aligns);
         out.n_aligned += c.n_aligned; out.n_anchors += c.n_anchors; out.poa_cells += c.poa_cells;
@@ -580,19 +747,13 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
     if (ctxs.empty()) ctxs = create_contexts(devs);
     const uint32_t n_slots = (uint32_t)ctxs.size();
     trace_mark("contexts created");
-    // the two settings below travel to the library through the environment: what was there before comes back at the end
-    struct env_keeper {
-        const char *name;
-        bool had;
-        std::string old;
-        explicit env_keeper(const char *n) : name(n), had(getenv(n) != nullptr), old(had ? getenv(n) : "") {}
-        ~env_keeper() { if (had) setenv(name, old.c_str(), 1); else unsetenv(name); }
-    } keep_fraction("VGA_POOL_FRACTION"), keep_threads("VGA_HOST_THREADS");
-    // contexts that share a GPU share its memory: each takes its part of the traceback pool
-    if (!devs.empty() && !getenv("VGA_POOL_FRACTION")) {
+    // contexts that share a GPU share its memory: each takes its part of the traceback pool (a per-context setting of the
+    // library; VGA_POOL_FRACTION in the environment still overrides it for diagnostics)
+    if (!devs.empty()) {
         size_t most = 1;
         for (int d : devs) most = std::max<size_t>(most, (size_t)std::count(devs.begin(), devs.end(), d));
-        if (most > 1) setenv("VGA_POOL_FRACTION", std::to_string(1.0 / (double)most).c_str(), 0);
+        if (most > 1)
+            for (vga_ctx *c : ctxs) (void)vga_ctx_set_pool_fraction(c, 1.0 / (double)most);
     }
     {
         vga_index_desc d;
@@ -602,10 +763,10 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
             if (vga_index_upload(c, &d) != VGA_OK) { const std::string e = vga_last_error(c); release(); throw Error(e); }
     }
     trace_mark("index uploaded");
-    // the library's worker threads (subgraph extraction, CIGAR strings) are per call: share the cores between the slots
+    // the library's worker threads (CIGAR strings, result copies) are per call: the slots share the cores
     if (n_slots > 1 && !getenv("VGA_HOST_THREADS")) {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        setenv("VGA_HOST_THREADS", std::to_string(std::max(2u, std::min(32u, hw / n_slots))).c_str(), 0);
+        for (vga_ctx *c : ctxs) (void)vga_ctx_set_host_threads(c, std::max(2u, std::min(32u, hw / n_slots)));
     }
     std::vector<uint64_t> len(inputs.size());
     for (size_t i = 0; i < inputs.size(); i++) len[i] = inputs[i].seq.size();
@@ -622,41 +783,39 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
     std::condition_variable cv;
     std::vector<uint8_t> done(plan.size(), 0), chains_done(plan.size(), 0);
     bool abort_writer = false, abort_workers = false;
-    std::string writer_err;
-    std::thread writer;
-    if (stream)
-        writer = std::thread([&]() {
+    const unsigned T_text = text_threads(n_slots);
+    // one writer per file (the chains of a chunk are ready long before its alignments, and neither should wait for the other's
+    // copy), each appending the chunks in read order with several copying threads (AppendFile)
+    std::string writer_err[2];
+    std::thread writer[2];
+    auto start_writer = [&](int which) {
+        writer[which] = std::thread([&, which]() {
             try {
-                std::ofstream fc(out_prefix + "-chains.gaf", std::ios::binary), fa;
-                if (!fc) throw Error("Couldn't create file " + out_prefix + "-chains.gaf");
-                if (opt.also_align) {
-                    fa.open(out_prefix + "-alignments.gaf", std::ios::binary);
-                    if (!fa) throw Error("Couldn't create file " + out_prefix + "-alignments.gaf");
-                }
-                auto put = [&](std::ofstream &f, std::vector<std::string> &pieces) {
-                    for (std::string &q : pieces) { f.write(q.data(), (std::streamsize)q.size()); std::string().swap(q); }
-                    if (!f) throw Error("Couldn't write the GAF files under " + out_prefix);
-                };
+                AppendFile f(out_prefix + (which == 0 ? "-chains.gaf" : "-alignments.gaf"));
                 for (size_t i = 0; i < plan.size(); i++) {
-                    {  // the chains of a chunk are ready long before its alignments
-                        std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&]() { return chains_done[i] || done[i] || abort_writer; });
-                        if (!chains_done[i] && !done[i]) return;
-                    }
-                    put(fc, parts[i].chains);
                     {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&]() { return done[i] || abort_writer; });
-                        if (!done[i]) return;
+                        cv.wait(lk, [&]() { return (which == 0 && chains_done[i]) || done[i] || abort_writer; });
+                        if (!(which == 0 && chains_done[i]) && !done[i]) return;
                     }
-                    if (opt.also_align) put(fa, parts[i].aligns);
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const uint64_t before = f.size();
+                    f.append(which == 0 ? parts[i].chains : parts[i].aligns, std::max(2u, T_text));
+                    if (getenv("VGA_TRACE"))
+                        fprintf(stderr, "[vgh-trace] %s of chunk %zu: %.1f MB appended in %.1f ms\n", which == 0 ? "chains GAF" : "alignments GAF", i,
+                                (double)(f.size() - before) / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
                 }
             } catch (const std::exception &e) {
-                writer_err = e.what();
+                writer_err[which] = e.what();
                 std::lock_guard<std::mutex> lk(mu);
                 abort_workers = true;  // (nothing that is still to be mapped could be written)
             }
         });
+    };
+    if (stream) {
+        start_writer(0);
+        if (opt.also_align) start_writer(1);
+    }
     // the last chunk of a slot: once its GPU work is done nothing needs the context any more.  A caller that is about to leave
     // the process (leave_contexts) has it torn down right then, beside the text and file work that is left -- the driver
     // takes about 5 ms per GB of pool to take the memory back, at hipFree or at exit alike
@@ -680,7 +839,7 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
                                 std::lock_guard<std::mutex> lk(destroyers_mu);
                                 destroyers.emplace_back([c]() { vga_ctx_destroy(c); });
                             };
-                        map_chunk(ctxs[slot], ix, inputs, plan[i].begin, plan[i].end, opt, parts[i], hooks);
+                        map_chunk(ctxs[slot], ix, inputs, plan[i].begin, plan[i].end, opt, parts[i], hooks, T_text);
                         { std::lock_guard<std::mutex> lk(mu); done[i] = 1; }
                         cv.notify_all();
                     }
@@ -692,16 +851,28 @@ MapOutput map_reads_multi(const Index &ix, const std::vector<QuerySequence> &inp
         });
     for (std::thread &t : workers) t.join();
     trace_mark("chunks mapped and aligned");
-    if (writer.joinable()) writer.join();
+    for (std::thread &w : writer)
+        if (w.joinable()) w.join();
     trace_mark("GAF files written");
-    // (leave_contexts: whatever the tear-down threads have not finished, the exit of the process finishes)
-    for (std::thread &t : destroyers) t.detach();
-    if (opt.leave_contexts) ctxs.clear();
-    else release();
+    bool any_error = false;
+    for (const std::string &e : errors) any_error = any_error || !e.empty();
+    for (const std::string &e : writer_err) any_error = any_error || !e.empty();
+    if (opt.leave_contexts && !any_error) {
+        // the caller leaves the process next (vgaligner: _exit once the files are closed): whatever the tear-down threads have not
+        // finished, the exit finishes
+        for (std::thread &t : destroyers) t.detach();
+        ctxs.clear();
+    } else {
+        // an error is reported by a normal return / exit path: no detached thread may still be inside the HIP runtime when its
+        // static destructors run, and no context may leak
+        for (std::thread &t : destroyers) t.join();
+        release();
+    }
     trace_mark("contexts destroyed");
     for (const std::string &e : errors)
         if (!e.empty()) throw Error(e);
-    if (!writer_err.empty()) throw Error(writer_err);
+    for (const std::string &e : writer_err)
+        if (!e.empty()) throw Error(e);
     MapOutput out;
     out.n_reads = inputs.size();
     out.n_devices = n_slots;

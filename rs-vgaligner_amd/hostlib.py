@@ -48,6 +48,8 @@ def load_library():
     L.vgh_gaf_alignment_record.argtypes = [C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32,
                                            C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p]
     L.vgh_gaf_alignment_record.restype = vp
+    L.vgh_textpath_replay.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_char_p, C.c_uint32, C.c_uint32,
+                                      C.POINTER(C.c_double)]
     L.vgh_free.argtypes = [vp]
     _lib = L
     return L
@@ -118,6 +120,19 @@ class HostIndex:
         self.L.vgh_free(cg)
         self.L.vgh_free(ag)
         return c, a, int(na.value)
+
+    def textpath_replay(self, ctx: binding.Context, names: Sequence[str], seqs: Sequence[str], out_prefix: str, repeat: int = 4,
+                        n_threads: int = 0) -> dict:
+        """diagnostics: one chunk mapped and aligned once, its GAF text put together and appended to two files `repeat` times"""
+        n = len(seqs)
+        nm = (C.c_char_p * n)(*[s.encode() for s in names])
+        sq = (C.c_char_p * n)(*[s.encode() for s in seqs])
+        out = (C.c_double * 6)()
+        rc = self.L.vgh_textpath_replay(ctx.h, self.h, n, nm, sq, out_prefix.encode(), repeat, n_threads, out)
+        if rc != 0:
+            raise HostError(self.L.vgh_last_error().decode())
+        return {"bytes": int(out[0]), "chains_bytes": int(out[1]), "seconds": out[2], "text_seconds": out[3], "write_seconds": out[4],
+                "threads": int(out[5]), "gb_per_s": out[0] / 1e9 / max(out[2], 1e-9)}
 
     def map_reads_multi(self, names: Sequence[str], seqs: Sequence[str], devices: Sequence[int] = (), chunk_reads: int = 32768,
                         max_gap: int = 1000, chain_min_n_anchors: int = 3, also_align: bool = True, align_best_n: int = 1,

@@ -21,7 +21,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert declared == set(p.binding.ABI_SYMBOLS), declared ^ set(p.binding.ABI_SYMBOLS)
     for sym in sorted(declared):
         assert hasattr(L, sym), f"libvga_hip.so does not export {sym}"
-    assert L.vga_abi_version() == 5
+    assert L.vga_abi_version() == 6
 
 
 # every struct of include/vga_hip.h and the ctypes class binding.py declares for it
