@@ -291,6 +291,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     poa_feed feed;
     feed.views.resize(n);
     std::vector<double> proxy(n, 0.0);
+    std::vector<float> west(n, 650.0f);  // the band-width term of the proxy (its floor: a graph about as long as the read)
     std::vector<uint8_t> klass(n, 0);  // 1: a very long problem (by its actual rows, known for the first part of the store), launched apart
     std::vector<uint32_t> launch_order(n);
     std::vector<sg_desc> descs(on_device ? n : 0);
@@ -319,7 +320,8 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         const double q_last = c1 > c0 ? (double)m->query_begin[a0 + m->chain_anchor_idx[c1 - 1]] + (double)k : (double)ql;
         const double uncovered = q_first + std::max(0.0, (double)ql - q_last);
         const double rows = (double)(hi > lo ? hi - lo : 0) + 1.6 * uncovered;
-        proxy[p] = rows * (650.0 + 0.3 * std::max(0.0, 0.85 * rows - (double)ql));
+        west[p] = (float)(650.0 + 0.3 * std::max(0.0, 0.85 * rows - (double)ql));
+        proxy[p] = rows * (double)west[p];
         feed.views[p] = {nullptr, nullptr, 0, nullptr, nullptr, 0, b->reads.data() + b->read_off[r], ql};
         if (on_device) {
             const uint64_t fa = a0 + m->chain_anchor_idx[c0], la = a0 + m->chain_anchor_idx[c1 - 1];
@@ -340,7 +342,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
             for (uint64_t i = 0; i < n; i++) w[i] = v[ord[i]];
             v.swap(w);
         };
-        permute(prob_read); permute(prob_chain); permute(proxy); permute(feed.views); permute(descs); permute(q_src);
+        permute(prob_read); permute(prob_chain); permute(proxy); permute(west); permute(feed.views); permute(descs); permute(q_src);
         for (uint64_t i = 0; i < n; i++) slot_of[ord[i]] = (uint32_t)i;
     }
     if (has_reverse)
@@ -358,8 +360,17 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         vga_timers_reset(ctx);
         feed.keep_timers = true;
         auto ta = std::chrono::steady_clock::now();
-        // the first launch takes 2 048 problems (poa_run, arena mode); small calls are prepared in one go
+        // the first launch takes 2 048 problems (poa_run, arena mode); small calls are prepared in one go -- and so are calls of
+        // narrow-band problems (rows ~ read length: the width estimate below stays at its floor; config 5), whose DP launches are
+        // short and whose subgraphs are cheap: with the second part beside the first launches on a throttled stream, those
+        // launches waited 2 x 160 ms for it in the command line tool (25 000 reads; the chains' path text is written on the GPU at
+        // the same time), against 13 ms for all of it up front
         uint64_t split = n > 3072 ? 2048 : n;
+        {
+            double wsum = 0;
+            for (uint64_t i = 0; i < n; i++) wsum += west[i];
+            if (n && wsum / (double)n <= 700.0) split = n;  // (config 5: 650-660; config 3: 1 500-2 500; config 4: in between and above)
+        }
         if (const char *e = getenv("VGA_SG_SPLIT")) { const long v = atol(e); split = v <= 0 ? n : std::min<uint64_t>(n, (uint64_t)v); }  // (0: one part)
         const int rc = sg_prepare(ctx, descs.data(), q_src.data(), n, split, b->d_reads, params->remain_rule, store);
         if (rc != VGA_OK) return rc;

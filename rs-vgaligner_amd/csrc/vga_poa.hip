@@ -1015,7 +1015,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 // k_poa_dp_t6 (vga_poa_t6.hpp): one wave per problem, the row in registers -- launches of narrow bands in chunk-pool
                 // mode with the fused traceback; what does not fit its window comes back with POA_ST_RETRY and runs below
                 const bool t6_forced = force && strstr(force, "t6");
-                const bool t6 = t5 && arena && sub_fused && !general && !giant && !(force && strstr(force, "t5")) && (t6_forced || mean_w <= 800.0);
+                const bool t6 = t5 && arena && sub_fused && !general && !giant && !(force && strstr(force, "t5")) && (t6_forced || (mean_w <= 800.0 && mw <= 1000.0));
                 if (t6) {
                     const size_t lds6 = poa_t6_lds_bytes<8>(lds_cols);
                     if (tr.on) fprintf(stderr, "[vga-trace] poa:     k_poa_dp_t6<8>: one wave per problem, LDS %zu B\n", lds6);
@@ -1070,7 +1070,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             // K4c: the strings and the node path are written where the operations are (vga_poa_text.hpp); what crosses PCIe now is a
             // record per problem and the counter of the arena -- the text itself follows when the host knows how much there is
             const uint64_t arena = std::min<uint64_t>(2ull * tot_ops + 64ull * nb + 4096ull, 0xF0000000ull);
-            chk(S.d_text.reserve(arena)); chk(S.d_touts.reserve(nb)); chk(S.d_tcur.reserve(1));
+            chk(S.d_text.reserve(arena + 16)); chk(S.d_touts.reserve(nb)); chk(S.d_tcur.reserve(1));
             chk(O.h_touts.reserve(nb)); chk(O.h_tcur.reserve(1));
             if (launch_err == hipSuccess) {
                 int t_tx = vga_timer_begin(ctx, "poa_text", 0, st);
@@ -1268,7 +1268,18 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             bool overflow = false;
             for (uint64_t i = cur.i0; i < cur.i1; i++) overflow = overflow || S.h_touts.p[i - cur.i0].flags == 2u;
             hipError_t ce = S.h_text.reserve(used + 16);
-            if (ce == hipSuccess && used) ce = hipMemcpyAsync(S.h_text.p, SL.d_text.p, used, hipMemcpyDeviceToHost, sarr[cur.slot]);
+            if (ce == hipSuccess && used) {
+                void *hd = nullptr;
+                if (!getenv("VGA_POA_TEXT_MEMCPY") && hipHostGetDevicePointer(&hd, S.h_text.p, 0) == hipSuccess && hd) {
+                    const uint64_t n16 = (used + 15) / 16;  // (both buffers are 16-byte aligned and hold 16 bytes of slack)
+                    hipLaunchKernelGGL(k_poa_text_to_host, dim3((unsigned)std::min<uint64_t>(256, (n16 + 255) / 256)), dim3(256), 0, sarr[cur.slot],
+                                       (const uint4 *)SL.d_text.p, (uint4 *)hd, n16);
+                    ce = hipGetLastError();
+                } else {
+                    (void)hipGetLastError();
+                    ce = hipMemcpyAsync(S.h_text.p, SL.d_text.p, used, hipMemcpyDeviceToHost, sarr[cur.slot]);
+                }
+            }
             if (ce == hipSuccess && overflow) {
                 if (tr.on) fprintf(stderr, "[vga-trace] poa:   the text arena was too small for some problems: their operations come back\n");
                 ce = S.h_ops.reserve(S.tot_ops);
@@ -1278,8 +1289,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 if (ce == hipSuccess) ce = hipMemcpyAsync(S.h_orow.p, SL.d_orow.p, S.tot_ops * 4, hipMemcpyDeviceToHost, sarr[cur.slot]);
                 if (ce == hipSuccess) ce = hipMemcpyAsync(S.h_seq.p, SL.d_seq32.p, S.tot_seq, hipMemcpyDeviceToHost, sarr[cur.slot]);
             }
+            const auto t_tx0 = std::chrono::steady_clock::now();
             if (ce == hipSuccess) ce = hipStreamSynchronize(sarr[cur.slot]);
             if (ce != hipSuccess) { launch_err = ce; break; }
+            if (tr.on) fprintf(stderr, "[vga-trace] poa:   text of the sub-batch: %.1f MB copied back in %.2f ms\n", (double)used / 1e6,
+                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_tx0).count());
             text_bytes += used + (cur.i1 - cur.i0) * sizeof(poa_text_out);
             if (overflow) text_bytes += 5 * S.tot_ops + S.tot_seq;
         } else
@@ -1364,7 +1378,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         // problems the 16-bit kernel stopped (a score near the int16 range) run again with 32-bit words
         for (uint64_t i = cur.i0; i < cur.i1; i++)
             if (S.h_outs.p[i - cur.i0].status == POA_ST_RETRY) retry.push_back(order[i]);
-        if (todo.empty() && inflight.empty() && !retry.empty()) {
+        if (!retry.empty()) {
+            // at once, beside the launches that are still to come: a pass of its own at the end would run for as long as its
+            // longest problem has rows with most of the GPU idle (config 5, first build of k_poa_dp_t6: 45 ms of a 170 ms call)
             const uint64_t a = order.size();
             for (uint32_t p : retry) order.push_back(p);
             if (tr.on) fprintf(stderr, "[vga-trace] poa: %zu problems handed back by the specialised DP kernel: re-run with the general one\n", retry.size());

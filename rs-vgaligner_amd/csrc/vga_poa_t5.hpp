@@ -432,19 +432,33 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
         const bool staged = !simple && r > 0 && !wide && q_plain;
         if (staged) {
             POA_MARK("row_stage");
+            // Chunk-pool mode addresses the pool from 0: a predecessor whose record holds no value row -- only a row that is not
+            // the last base of a node can be one, and no predecessor list names such a row -- would be read at address 0.  A
+            // variant build that sent every row through the single-predecessor paths took `ps` of a several-predecessor node
+            // (an index into the predecessor list) for a row and faulted exactly there ("the nomulti fault").  Such a
+            // problem is given up instead, and the loads below test the address.
+            if (chunked) {
+                bool no_row = false;
+                for (int t = 0; t < np; t++) no_row |= t5_uniform64(R[np == 1 ? sp : plist[ps + t]].voff) == 0;
+                if (__builtin_expect(no_row, 0)) st |= ST_FAILED;
+            }
             for (int c0 = 0; c0 < W; c0 += STEP) {
                 const int c = c0 + 4 * tid;
                 const int j0 = bal + c;
                 if (j0 <= end && np == 1) {
                     // one predecessor: its cells as they are, 4 POA_NEG outside its band
                     const int bp = __builtin_amdgcn_readfirstlane(R[sp].beg), ep = __builtin_amdgcn_readfirstlane(R[sp].end);
-                    const uint8_t *Vq = pool + t5_uniform64(R[sp].voff);
+                    const uint64_t vq_off = t5_uniform64(R[sp].voff);
+                    const uint8_t *Vq = pool + vq_off;
+                    // (the address is tested through the offset: `pool` is a null pointer in chunk-pool mode, and a compiler may
+                    // decide what a comparison of null + offset with null gives)
+                    const bool vq_ok = !chunked || vq_off != 0;
                     const int balq = bp & ~3;
                     const int Wq = (ep - balq + 1 + 3) & ~3;
                     const int idx = j0 - balq;
                     int4 hv = make_int4(T4_NEG, T4_NEG, T4_NEG, T4_NEG);
                     uint2 gg = make_uint2(0u, 0u);
-                    if (idx >= 0 && idx < Wq) {
+                    if (idx >= 0 && idx < Wq && vq_ok) {
                         hv = *(const int4 *)((const int32_t *)Vq + idx);
                         gg = *(const uint2 *)(Vq + 4ll * Wq + 2ll * idx);
                     }
@@ -457,7 +471,7 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
                     *(int4 *)(Hs + (j0 & win_mask)) = hv;
                     *(uint2 *)(Gs + (j0 & win_mask)) = gg;
                     if (c == 0 && bal > 0) {
-                        const int wl = (idx >= 1 && idx - 1 < Wq) ? ((const int32_t *)Vq)[idx - 1] : 0;
+                        const int wl = (idx >= 1 && idx - 1 < Wq && vq_ok) ? ((const int32_t *)Vq)[idx - 1] : 0;
                         Hs[(bal - 1) & win_mask] = (unsigned)(j0 - 1 - bp) <= pspan ? wl : T4_NEG;
                     }
                 } else if (j0 <= end) {
@@ -468,9 +482,10 @@ void k_poa_dp_t5(const poa_prob *__restrict__ probs, const char *__restrict__ qu
                     for (int t = 0; t < np; t++) {
                         const uint32_t p = np == 1 ? sp : plist[ps + t];
                         const int bp = __builtin_amdgcn_readfirstlane(R[p].beg), ep = __builtin_amdgcn_readfirstlane(R[p].end);
-                        const uint8_t *Vq = pool + t5_uniform64(R[p].voff);
+                        const uint64_t vq_off = t5_uniform64(R[p].voff);
+                        const uint8_t *Vq = pool + vq_off;
                         const int balq = bp & ~3;
-                        const int Wq = (ep - balq + 1 + 3) & ~3;
+                        const int Wq = (!chunked || vq_off != 0) ? (ep - balq + 1 + 3) & ~3 : 0;
                         const int idx = j0 - balq;
                         int4 hv = make_int4(0, 0, 0, 0);
                         uint2 gg = make_uint2(0u, 0u);

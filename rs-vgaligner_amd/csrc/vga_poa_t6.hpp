@@ -330,9 +330,11 @@ __global__ __launch_bounds__(64) void k_poa_dp_t6(const poa_prob *__restrict__ p
                 const int jl = nbase + CPL * (lane + 64 * s);
                 if (np == 1) {
                     const int bp = __builtin_amdgcn_readfirstlane(R[ps].beg), ep = __builtin_amdgcn_readfirstlane(R[ps].end);
-                    const uint8_t *Vq = (const uint8_t *)poa_uniform_u64(R[ps].voff);
+                    const uint64_t vq_off = poa_uniform_u64(R[ps].voff);
+                    const uint8_t *Vq = (const uint8_t *)vq_off;
+                    if (__builtin_expect(vq_off == 0, 0)) failed = true;  // (a predecessor without a value row: vga_poa_t5.hpp, staging)
                     const int balq = bp & ~3;
-                    const int Wq = (ep - balq + 1 + 3) & ~3;
+                    const int Wq = vq_off != 0 ? (ep - balq + 1 + 3) & ~3 : 0;
                     const unsigned pspan = (unsigned)(ep - bp);
 #pragma unroll
                     for (int q = 0; q < Q; q++) {
@@ -369,9 +371,11 @@ __global__ __launch_bounds__(64) void k_poa_dp_t6(const poa_prob *__restrict__ p
                     for (int t = 0; t < np; t++) {
                         const uint32_t p = plist[ps + t];
                         const int bp = __builtin_amdgcn_readfirstlane(R[p].beg), ep = __builtin_amdgcn_readfirstlane(R[p].end);
-                        const uint8_t *Vq = (const uint8_t *)poa_uniform_u64(R[p].voff);
+                        const uint64_t vq_off = poa_uniform_u64(R[p].voff);
+                        const uint8_t *Vq = (const uint8_t *)vq_off;
+                        if (__builtin_expect(vq_off == 0, 0)) failed = true;
                         const int balq = bp & ~3;
-                        const int Wq = (ep - balq + 1 + 3) & ~3;
+                        const int Wq = vq_off != 0 ? (ep - balq + 1 + 3) & ~3 : 0;
                         const unsigned pspan = (unsigned)(ep - bp);
 #pragma unroll
                         for (int q = 0; q < Q; q++) {

@@ -187,3 +187,12 @@ __global__ __launch_bounds__(64) void k_poa_text(uint32_t n, const poa_prob *__r
     T.flags = 1u;
     if (lane == 0) touts[pi] = T;
 }
+
+// The second half of K4c's hand-over: the text (its length is known to the host by now) goes to pinned host memory through a
+// KERNEL, not through hipMemcpyAsync.  A copy issued while another sub-batch is in flight lands in a DMA queue behind that
+// sub-batch's own result copies, which wait for its DP kernel -- 35 ms for 18 MB on config 5 (measured in the command line
+// tool); 16-byte loads and stores from the compute units cross PCIe at once.
+__global__ __launch_bounds__(256) void k_poa_text_to_host(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint64_t n16)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256u) dst[i] = src[i];
+}

@@ -164,3 +164,59 @@ def test_bench_two_ranks_under_torch_distributed_on_one_gpu():
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["steps"] == 1
     assert j["whole_job"]["reads"] == 600 and 590 <= j["whole_job"]["aligned"] <= 600
     assert abs(j["value"] - j["whole_job"]["aligned"] / (j["ms_per_step"] * 1e-3)) <= 0.01 * j["value"]
+
+
+@pytest.mark.gpu
+def test_cli_eight_contexts_on_one_gpu_rehearse_an_eight_gpu_node(tmp_path, config4_gfa):
+    """Eight device slots as `--devices all` gives them on an 8-GPU node, rehearsed on the one GPU: `vgaligner map --devices
+    0,0,0,0,0,0,0,0 --chunk-reads 1500` -- eight contexts and eight host threads, each context told its eighth of the GPU's memory
+    (vga_ctx_set_pool_fraction) and of the host's threads (vga_ctx_set_host_threads), chunk pools that start small and grow under
+    their keeper threads -- on 12 000 full-length reads of the merged HLA graph, against one context: byte-identical GAF files in
+    read order (src/map.rs:56-111,162-167).  Wall times of both runs are printed (pytest -s; round 4 on the GPU box: 5.7 s against
+    12.1 s -- eight contexts time-slice one GPU, each creates its pool, uploads the index and runs its own longest problems) and
+    must stay within a factor of 3: what the test guards against is the small-share cliff of round 3 (a context with a fifth of
+    the pool ran 40x slower before the keeper thread)."""
+    import time
+    p = pkg()
+    d = str(tmp_path)
+    reads = p.readsim.config3_reads(config4_gfa, 12000)
+    fa = os.path.join(d, "r.fa")
+    p.readsim.write_fasta(reads, fa)
+    run(["index", "-i", config4_gfa, "-k", "11", "-o", os.path.join(d, "hla")], d)
+    base = ["map", "-i", os.path.join(d, "hla"), "-f", fa, "-p", "abpoa", "-D", "-G", config4_gfa]
+    t0 = time.perf_counter()
+    one = run(base + ["-o", os.path.join(d, "one"), "--device", "0", "--chunk-reads", "0"], d)
+    t1 = time.perf_counter()
+    eight = run(base + ["-o", os.path.join(d, "eight"), "--devices", "0,0,0,0,0,0,0,0", "--chunk-reads", "1500"], d)
+    t2 = time.perf_counter()
+    print("one context %.2f s, eight contexts %.2f s" % (t1 - t0, t2 - t1))
+    import re
+    assert "1 GPU context(s), 1 batch(es)" in one.stderr
+    mo = re.search(r"8 GPU context\(s\), (\d+) batch\(es\)", eight.stderr)  # (slices are balanced by bases: some hold more than 1 500 reads)
+    assert mo and 8 <= int(mo.group(1)) <= 16, eight.stderr
+    for suffix in ("-chains.gaf", "-alignments.gaf"):
+        a, b = open(os.path.join(d, "one" + suffix)).read(), open(os.path.join(d, "eight" + suffix)).read()
+        assert a == b and a.count("\n") >= 12000
+    al = open(os.path.join(d, "eight-alignments.gaf")).read().splitlines()
+    assert [ln.split("\t")[0] for ln in al] == [r.name for r in reads]
+    assert sum(1 for ln in al if ln.split("\t")[5] != "*") >= 11900
+    assert t2 - t1 <= 3.0 * (t1 - t0) + 1.0, (t1 - t0, t2 - t1)
+
+
+@pytest.mark.gpu
+def test_bench_four_ranks_under_torch_distributed_on_one_gpu():
+    """bench.py --gpus 4 under torch.distributed.run (the driver's command for N = 4), rehearsed on the one GPU: the launcher is
+    started before anything touches the GPU, VGA_BENCH_REHEARSAL=1 lets the four ranks share it (gloo for the barrier and the
+    max-over-ranks reduction).  One JSON line, n_gpus 4, the four ranks' reads summed in whole_job, value = that sum over the
+    slowest rank's time."""
+    env = dict(os.environ, VGA_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", VGA_POOL_FRACTION="0.2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--reads", "200", "--cpu-sample", "0"]
+    pr = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 4 and j["scaling"] == "weak" and j["steps"] == 1
+    assert j["whole_job"]["reads"] == 800 and j["whole_job"]["ranks"] == 4 and 790 <= j["whole_job"]["aligned"] <= 800
+    assert abs(j["value"] - j["whole_job"]["aligned"] / (j["ms_per_step"] * 1e-3)) <= 0.01 * j["value"]

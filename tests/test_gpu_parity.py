@@ -501,14 +501,16 @@ def _fallback_problems(rng):
                                  {"VGA_POA_TB": "wave"}, {"VGA_POOL_BYTES": "300000000"}, {"VGA_POA_SUB": "7"}, {"VGA_POA_WINDOW": "256"},
                                  {"VGA_POA_NT": "512"}, {"VGA_POA_NT": "1024"}, {"VGA_POA_NT": "512", "VGA_POA_ARENAS": "0"},
                                  {"VGA_SG_SPLIT": "1"}, {"VGA_SG_SPLIT": "2", "VGA_POA_SUB": "2", "VGA_POOL_BYTES": "300000000", "VGA_POA_ARENAS": "0"},
-                                 {"VGA_POA_KERNEL": "t6"}, {"VGA_POA_KERNEL": "t6,generic"}, {"VGA_POA_KERNEL": "t5"}],
+                                 {"VGA_POA_KERNEL": "t6"}, {"VGA_POA_KERNEL": "t6,generic"}, {"VGA_POA_KERNEL": "t5"},
+                                 {"VGA_POA_TEXT": "host"}, {"VGA_POA_TEXT_MEMCPY": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_poa_paths_the_library_can_fall_back_to(oracle, ctx, drb1, monkeypatch, env):
     """the configurations poa_run selects by itself when it has to -- classic pool instead of arenas (problems too large for
     an arena), k_poa_dp_lds (gap penalties beyond the byte range of k_poa_dp_t4), a traceback kernel of its own, a pool so
     small that sub-batches are re-queued, tiny sub-batches, a narrow LDS window (HBM detour of wide rows), the workgroup sizes of large launches (512) and of
     very long problems (1 024), the one-wave-per-problem kernel of narrow bands on every launch (k_poa_dp_t6: what does not fit its
-    window comes back and runs in k_poa_dp_t5) and switched off, the subgraph store
+    window comes back and runs in k_poa_dp_t5) and switched off, cs / CIGAR / node paths from host threads instead of k_poa_text (and
+    its text fetched by hipMemcpy instead of the copy kernel), the subgraph store
     in two parts (the second prepared beside the first launch) with launches and re-runs that draw on both -- forced
     through their environment switches and held to the same parity"""
     for k, v in env.items():
@@ -620,3 +622,37 @@ def test_align_best_of_n_chains(oracle, ctx, drb1):
             assert (int(f[6]), int(f[7]), int(f[8]), int(f[10])) == (
                 int(al.path_length[r]), int(al.path_start[r]), int(al.path_end[r]), int(al.block_length[r]))
         assert al.poa_cells == st["poa_cells"], f"best_n {best_n}: the same chains were aligned"
+
+
+def test_alignment_fields_come_from_the_device_and_settings_are_per_context(oracle, drb1):
+    """K4c (k_poa_text): vga_align_batch ships cs / CIGAR / deduplicated node paths as text -- far fewer bytes than the raw
+    traceback operations (5 B per alignment column) -- and both routes give the oracle's records.  The same call runs on a
+    context with its own pool share and host thread count (vga_ctx_set_pool_fraction / vga_ctx_set_host_threads, ABI 6), which
+    reject values outside their ranges."""
+    _, ix = drb1
+    c = pkg().Context(0)
+    try:
+        c.set_pool_fraction(0.25)
+        c.set_host_threads(2)
+        for bad in (0.0, 1.5, -1.0):
+            with pytest.raises(pkg().VgaError):
+                c.set_pool_fraction(bad)
+        with pytest.raises(pkg().VgaError):
+            c.set_host_threads(5000)
+        upload_oracle_index(c, ix)
+        reads = pkg().readsim.simulate_reads(DRB1, 24, 6000, 0.03, 0.03, 0.04, seed=91)
+        _check_align(oracle, c, ix, reads)
+        seqs = [r.seq for r in reads]
+        b = c.batch(seqs)
+        dev = b.map_align_raw()
+        os.environ["VGA_POA_TEXT"] = "host"
+        try:
+            host = b.map_align_raw()
+        finally:
+            del os.environ["VGA_POA_TEXT"]
+        assert dev["aligned"] == host["aligned"] == len(reads)
+        assert dev["cigar_bytes"] == host["cigar_bytes"] and dev["path_bases"] == host["path_bases"]
+        # text: a few bytes per alignment event; operations: 5 bytes per column (+ the gathered node sequences)
+        assert dev["result_bytes"] * 4 < host["result_bytes"], (dev["result_bytes"], host["result_bytes"])
+    finally:
+        c.close()
