@@ -355,6 +355,20 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     if (!on_device)
         for (auto &sc : scratch) sc.best.assign((size_t)(ctx->index.n_nodes + 2) * 2, 0);
     sg_store store;
+    // ... and so do problems with fewer rows whose band will be as wide as the query (a subgraph several times longer than the
+    // read: the band spans what separates the path from the diagonal `qlen - remain`): in an ordinary launch every row of
+    // theirs is wider than the LDS window and takes the HBM detour -- 24-27 us per row, 0.83-0.99 s for 34 000-37 000 rows on
+    // config 4, as long as the 107 000-row problem takes in the launch of the long ones.  The product rows x expected width
+    // (poa_run's estimate: from the longest source-sink path) decides.
+    const double giant_cells = getenv("VGA_GIANT_CELLS") ? atof(getenv("VGA_GIANT_CELLS")) : 1.5e8;
+    std::function<uint8_t(uint64_t)> is_giant = [&](uint64_t i) -> uint8_t {  // (function scope: feed.dev_rest calls it from inside poa_run)
+        const sg_sum &sm = store.sum[i];
+        if (sm.N >= 40000u) return 1;
+        const double ql = (double)feed.views[i].qlen;
+        const double w = params->wb < 0 ? ql : (double)params->wb + (double)(uint64_t)(params->wf * ql);
+        const double ew = std::min(ql + 1.0, 2.0 * w + 431.0 + 0.3 * std::abs((double)sm.longest - ql));
+        return (double)sm.N * ew >= giant_cells ? 1 : 0;
+    };
     index_view iv_all(ctx->index);
     if (on_device) {
         vga_timers_reset(ctx);
@@ -382,7 +396,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         // first, in a launch of their own with 512 threads and an 8 192-column window (poa_run).  The order inside the
         // first part is free -- the store is addressed by problem index.
         for (uint64_t i = 0; i < n; i++) launch_order[i] = (uint32_t)i;
-        for (uint64_t i = 0; i < store.split; i++) klass[i] = store.sum[i].N >= 40000u ? 1 : 0;
+        for (uint64_t i = 0; i < store.split; i++) klass[i] = is_giant(i);
         std::stable_sort(launch_order.begin(), launch_order.begin() + (long)store.split, [&](uint32_t x, uint32_t y) { return klass[x] > klass[y]; });
         feed.order = launch_order.data();
         feed.klass = klass.data();
@@ -391,7 +405,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
             const int rc2 = sg_prepare_rest(ctx, store);
             sub_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
             if (rc2 == VGA_OK) {  // none of the second part's problems has been staged yet: its very long ones move to its front
-                for (uint64_t i = store.split; i < n; i++) klass[i] = store.sum[i].N >= 40000u ? 1 : 0;
+                for (uint64_t i = store.split; i < n; i++) klass[i] = is_giant(i);
                 std::stable_sort(launch_order.begin() + (long)store.split, launch_order.end(), [&](uint32_t x, uint32_t y) { return klass[x] > klass[y]; });
             }
             return rc2;

@@ -927,7 +927,11 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                     while (w2 < 4096 && (double)w2 < mw * 1.25 + 16.0) w2 <<= 1;
                     want = w2;
                 }
-                if (giant) want = 8192;
+                // the longest problems of a call have a CU almost to themselves (16 waves, 55-66 KB of LDS) and are often as wide as the
+                // query: every column in LDS (62 % of the cells of config 4's 107 000-row problem lie in rows wider than 8 192 columns,
+                // 100 % of those of its 34 000-row problems: 24-27 us per row through the HBM detour against 7.6).  A query too long for
+                // that falls back to the largest window that fits (below)
+                if (giant) want = 0;
                 if (giant && getenv("VGA_POA_GIANT_WINDOW")) want = (uint32_t)strtoul(getenv("VGA_POA_GIANT_WINDOW"), nullptr, 10);  // (0: every column)
                 const char *ew = getenv("VGA_POA_WINDOW");
                 if (ew) want = (uint32_t)strtoul(ew, nullptr, 10);
