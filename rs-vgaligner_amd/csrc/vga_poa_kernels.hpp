@@ -123,7 +123,10 @@ struct poa_chunk_pool {
 };
 __device__ __forceinline__ uint64_t poa_chunk_addr(const poa_chunk_pool &C, uint32_t idx)
 {
-    return C.seg_base[idx >> C.cps_log2] + ((uint64_t)(idx & ((1u << C.cps_log2) - 1u)) << 20);
+    // (an agent-scope load: the table grows while this kernel runs -- a new segment's entry is written by a copy on another stream
+    // before its chunks are listed -- and a plain load through the const pointer may become a scalar load, whose cache the
+    // acquire of poa_chunk_pop does not invalidate)
+    return __hip_atomic_load(C.seg_base + (idx >> C.cps_log2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ((uint64_t)(idx & ((1u << C.cps_log2) - 1u)) << 20);
 }
 // one thread: pop a chunk, starting at this workgroup's home list and going round; waits (bounded, ~0.1 s) while all lists
 // are empty -- chunks come back as other workgroups finish, and new segments arrive from the host

@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void k_poa_dp_t6(const poa_prob *__restrict__ p
             if (own_tail == POA_NIL) own_tail = idx;
             own_chunks++;
             uint64_t a = 0;
-            if (lane == 0) a = __hip_atomic_load(A.cp.seg_base + (idx >> A.cp.cps_log2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ((uint64_t)(idx & ((1u << A.cp.cps_log2) - 1u)) << 20);
+            if (lane == 0) a = poa_chunk_addr(A.cp, idx);
             dcur = poa_uniform_u64(a);
             drem = (uint32_t)POA_CHUNK;
         }
