@@ -368,21 +368,25 @@ extern "C" int vga_align_prepare(vga_ctx *ctx, uint64_t n_reads, uint32_t max_re
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return VGA_OK;
     uint64_t avail = free_b > (16ull << 30) ? (uint64_t)((double)free_b * 0.85) : free_b / 4;
+    double share = 1.0;  // of the GPU: its memory, and the workgroups that will be resident at a time
     {
         // contexts that share a GPU: vga_ctx_set_pool_fraction (the driver: 1 / their number); VGA_POOL_FRACTION is the diagnostic override
         double f = ctx->pool_fraction;
         if (const char *fr = getenv("VGA_POOL_FRACTION")) f = atof(fr);
-        if (f > 0.0 && f < 1.0) avail = (uint64_t)((double)avail * f);
+        if (f > 0.0 && f < 1.0) { avail = (uint64_t)((double)avail * f); share = f; }
     }
     if (const char *env_pool = getenv("VGA_POOL_BYTES")) avail = std::min<uint64_t>(avail, strtoull(env_pool, nullptr, 10));
     const uint64_t state_size = poa_state_size(max_read_len);
-    uint64_t ns = std::min<uint64_t>(16ull * (uint64_t)ctx->n_cu, std::max<uint64_t>(n_reads, 64));
+    // (a context that shares the GPU with others has its share of the resident workgroups, which is what the chunk pool is sized
+    // for below: eight contexts that each provided for a whole GPU spent 5.3 s of a 12 s run in allocations that the driver
+    // serialises and clears at 40 GB/s)
+    uint64_t ns = std::min<uint64_t>(16ull * (uint64_t)ctx->n_cu, std::max<uint64_t>(n_reads, 64));  // (state regions: one per workgroup of a launch -- fewer, and the rest of a launch spins for one on CUs the holders need)
     while (ns > 1 && ns * state_size > avail / 4) ns /= 2;
     if (ns * state_size > avail / 2) return VGA_OK;
     // the direction rows of a read of L bases against its subgraph: about 1.7 L rows of a band about 0.25 L wide plus the kept
     // value rows -- half of what the resident problems of such a call will hold (poa_run asks for the rest, from its probe)
     const double per_problem = 0.5 * (double)max_read_len * (double)max_read_len + 2.0 * (double)POA_CHUNK;
-    const uint64_t resident = std::min<uint64_t>(n_reads, 6ull * (uint64_t)ctx->n_cu);
+    const uint64_t resident = std::min<uint64_t>(n_reads, std::max<uint64_t>(32, (uint64_t)(6.0 * (double)ctx->n_cu * share)));
     uint64_t pool_want = (uint64_t)std::min<double>((double)resident * per_problem * 0.35, (double)avail / 4.0) & ~(POA_CHUNK - 1);
     if (pool_want < 16 * POA_CHUNK) pool_want = 0;
     W.prepare_async(ns * state_size, pool_want);
@@ -538,6 +542,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     // what this context may take of the GPU: everything else it allocates (staging of three sub-batches, the subgraph store,
     // the map workspace) keeps 15 % of what is free, at least 16 GB -- two processes sharing a GPU otherwise starve each other
     uint64_t avail_pool = 0;
+    double gpu_share = 1.0;  // (contexts that share the GPU: this one's part of its memory and of the resident workgroups)
     {
         size_t free_b = 0, total_b = 0;
         POA_CHECK(hipMemGetInfo(&free_b, &total_b));
@@ -550,7 +555,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         {
             double f = ctx->pool_fraction;
             if (const char *fr = getenv("VGA_POOL_FRACTION")) f = atof(fr);
-            if (f > 0.0 && f < 1.0) avail_pool = (uint64_t)((double)avail_pool * f);
+            if (f > 0.0 && f < 1.0) { avail_pool = (uint64_t)((double)avail_pool * f); gpu_share = f; }
         }
         if (const char *env_pool = getenv("VGA_POOL_BYTES")) avail_pool = std::min<uint64_t>(avail_pool, strtoull(env_pool, nullptr, 10));
     }
@@ -607,7 +612,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         uint64_t ns = std::min<uint64_t>(16ull * (uint64_t)ctx->n_cu, std::max<uint64_t>(n, 64));  // (16 two-wave workgroups per CU at most)
         if (const char *e = getenv("VGA_POA_ARENAS")) ns = std::min<uint64_t>(ns, std::max<uint64_t>(1, strtoull(e, nullptr, 10)));
         while (ns > 1 && ns * state_size > avail_pool / 4) ns /= 2;
-        const uint64_t resident = std::min<uint64_t>(n, 6ull * (uint64_t)ctx->n_cu);
+        const uint64_t resident = std::min<uint64_t>(n, std::max<uint64_t>(32, (uint64_t)(6.0 * (double)ctx->n_cu * gpu_share)));
         double fill = 0.7;
         if (const char *e = getenv("VGA_POOL_FILL")) fill = atof(e);
         uint64_t want = (uint64_t)((double)resident * probe_mean * W.pool_scale * fill) + 64 * POA_CHUNK;
