@@ -361,9 +361,12 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     // config 4, as long as the 107 000-row problem takes in the launch of the long ones.  The product rows x expected width
     // (poa_run's estimate: from the longest source-sink path) decides.
     const double giant_cells = getenv("VGA_GIANT_CELLS") ? atof(getenv("VGA_GIANT_CELLS")) : 1.5e8;
+    // (rows: 24 000 and more -- config 3's longest problems have 21 000-22 000 rows and stay in the ordinary launches; config 4's
+    // bubble-rich problems of 24 000-38 000 rows, whose band is as wide as the query on every row, do not)
+    const uint32_t giant_rows = getenv("VGA_GIANT_ROWS") ? (uint32_t)atol(getenv("VGA_GIANT_ROWS")) : 24000u;
     std::function<uint8_t(uint64_t)> is_giant = [&](uint64_t i) -> uint8_t {  // (function scope: feed.dev_rest calls it from inside poa_run)
         const sg_sum &sm = store.sum[i];
-        if (sm.N >= 40000u) return 1;
+        if (sm.N >= giant_rows) return 1;
         const double ql = (double)feed.views[i].qlen;
         const double w = params->wb < 0 ? ql : (double)params->wb + (double)(uint64_t)(params->wf * ql);
         const double ew = std::min(ql + 1.0, 2.0 * w + 431.0 + 0.3 * std::abs((double)sm.longest - ql));

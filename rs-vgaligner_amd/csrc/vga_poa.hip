@@ -39,6 +39,7 @@
 #include "vga_poa_t4.hpp"
 #include "vga_poa_t5.hpp"
 #include "vga_poa_t6.hpp"
+#include "vga_poa_t7.hpp"
 #include "vga_poa_text.hpp"
 
 // One workgroup per staged problem: copies its node table, predecessor rows, sink rows, bases and query from the device
@@ -1025,7 +1026,41 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 // mode with the fused traceback; what does not fit its window comes back with POA_ST_RETRY and runs below
                 const bool t6_forced = force && strstr(force, "t6");
                 const bool t6 = t5 && arena && sub_fused && !general && !giant && !(force && strstr(force, "t5")) && (t6_forced || (mean_w <= 800.0 && mw <= 1000.0));
-                if (t6) {
+                // k_poa_dp_t7 (vga_poa_t7.hpp): t6's eight-columns-per-lane row for bands that need several waves.  The launch of a call's
+                // longest problems runs it (1 024 threads: 8 192 columns per step, every column in LDS): their rows are a serial chain
+                // on a CU of their own, and a t7 row takes 4.9-5.9 us where a t5 row of the same 6 000-column band takes 7.6 (config 4:
+                // 10 900 -> 13 600-13 850 reads/s).  On ordinary launches it issues as many instructions per cell as t5 and loses to the
+                // problems that leave its window (config 3: 7 700 against 9 450 reads/s), so there it is opt-in (VGA_POA_KERNEL=t7)
+                const bool t7 = t5 && arena && sub_fused && !general && !t6 &&
+                                ((force && strstr(force, "t7")) ||
+                                 (giant && !(force && strstr(force, "t5")) && !(getenv("VGA_POA_T7_GIANTS") && atoi(getenv("VGA_POA_T7_GIANTS")) == 0)));
+                if (t7) {
+                    int nt7 = giant ? 1024 : 256;
+                    if (const char *e = getenv("VGA_POA_T7_NT")) nt7 = atoi(e);
+                    uint32_t w7 = 4096;
+                    while (w7 < lds_cols && (giant || (double)w7 < mw * 1.6 + 64.0)) w7 <<= 1;  // (a power of two that holds the launch's widest expected row)
+                    if (const char *e = getenv("VGA_POA_T7_WINDOW")) w7 = (uint32_t)strtoul(e, nullptr, 10);
+                    while (poa_t5_lds_bytes(w7, lds_cols, nt7) > lds_limit && w7 > 1024) w7 >>= 1;
+                    const size_t lds7 = poa_t5_lds_bytes(w7, lds_cols, nt7);
+                    poa_t5_args t7a = t5a;
+                    t7a.hg_cols = w7; t7a.win_mask = w7 - 1;
+                    if (tr.on) fprintf(stderr, "[vga-trace] poa:     k_poa_dp_t7<%d>: window %u columns, LDS %zu B\n", nt7, w7, lds7);
+#define POA_T7_LAUNCH(T)                                                                                                         \
+    case T:                                                                                                                      \
+        if (def_pen) {                                                                                                           \
+            chk(hipFuncSetAttribute((const void *)k_poa_dp_t7<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7)); \
+            hipLaunchKernelGGL((k_poa_dp_t7<T, true>), dim3(nb), dim3(T), lds7, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t7a); \
+        } else {                                                                                                                 \
+            chk(hipFuncSetAttribute((const void *)k_poa_dp_t7<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7)); \
+            hipLaunchKernelGGL((k_poa_dp_t7<T, false>), dim3(nb), dim3(T), lds7, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t7a); \
+        }                                                                                                                        \
+        break;
+                    switch (nt7) {
+                        POA_T7_LAUNCH(128) POA_T7_LAUNCH(256) POA_T7_LAUNCH(512) POA_T7_LAUNCH(1024)
+                    default: chk(hipErrorInvalidValue);
+                    }
+#undef POA_T7_LAUNCH
+                } else if (t6) {
                     const size_t lds6 = poa_t6_lds_bytes<8>(lds_cols);
                     if (tr.on) fprintf(stderr, "[vga-trace] poa:     k_poa_dp_t6<8>: one wave per problem, LDS %zu B\n", lds6);
                     if (def_pen) {

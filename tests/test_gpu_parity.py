@@ -502,7 +502,9 @@ def _fallback_problems(rng):
                                  {"VGA_POA_NT": "512"}, {"VGA_POA_NT": "1024"}, {"VGA_POA_NT": "512", "VGA_POA_ARENAS": "0"},
                                  {"VGA_SG_SPLIT": "1"}, {"VGA_SG_SPLIT": "2", "VGA_POA_SUB": "2", "VGA_POOL_BYTES": "300000000", "VGA_POA_ARENAS": "0"},
                                  {"VGA_POA_KERNEL": "t6"}, {"VGA_POA_KERNEL": "t6,generic"}, {"VGA_POA_KERNEL": "t5"},
-                                 {"VGA_POA_TEXT": "host"}, {"VGA_POA_TEXT_MEMCPY": "1"}],
+                                 {"VGA_POA_TEXT": "host"}, {"VGA_POA_TEXT_MEMCPY": "1"},
+                                 {"VGA_POA_KERNEL": "t7"}, {"VGA_POA_KERNEL": "t7,generic"}, {"VGA_POA_KERNEL": "t7", "VGA_POA_T7_NT": "128", "VGA_POA_T7_WINDOW": "1024"},
+                                 {"VGA_POA_KERNEL": "t7", "VGA_POA_T7_NT": "1024"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_poa_paths_the_library_can_fall_back_to(oracle, ctx, drb1, monkeypatch, env):
     """the configurations poa_run selects by itself when it has to -- classic pool instead of arenas (problems too large for
