@@ -32,6 +32,7 @@
 #include <type_traits>
 #include <chrono>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <thread>
 
@@ -41,6 +42,21 @@
 #include "vga_poa_t6.hpp"
 #include "vga_poa_t7.hpp"
 #include "vga_poa_text.hpp"
+
+// The dynamic LDS a kernel may ask for is an attribute of the function for the whole process (per device), and contexts on other
+// host threads launch the same kernels with other sizes: the limit only ever goes up, under a lock, so that no launch meets a
+// limit that another thread has just set lower than what it asks for
+static hipError_t poa_allow_lds(int device, const void *fn, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> cur;
+    std::lock_guard<std::mutex> g(mu);
+    size_t &c = cur[std::make_pair(device, fn)];
+    if (bytes <= c) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) c = bytes;
+    return e;
+}
 
 // One workgroup per staged problem: copies its node table, predecessor rows, sink rows, bases and query from the device
 // store of vga_subgraph.hip (and the batch's reads) to where this sub-batch's poa_prob says they are.
@@ -231,7 +247,7 @@ struct poa_ws {
     uint64_t seg_bytes = 1ull << POA_SEG_LOG2;
     // chunk pool (device side)
     vga_dbuf<unsigned long long> d_head;  // the free-list heads (POA_LISTS of them, a cache line apart), then the statistics
-    vga_dbuf<uint32_t> d_next_chunk, d_slot_flag;
+    vga_dbuf<uint32_t> d_next_chunk, d_slot_flag, d_owner;
     vga_hbuf<uint32_t> h_short;           // poa_chunk_pool::short_flag
     vga_hbuf<uint64_t> h_seg_base;        // staging of ...
     vga_dbuf<uint64_t> d_seg_base;        // ... the segment table the kernels read (an entry is copied before its chunks are listed)
@@ -245,7 +261,8 @@ struct poa_ws {
     {
         std::vector<unsigned long long> init(POA_LISTS * POA_LIST_STRIDE + 16, 0ull);
         for (int l = 0; l < POA_LISTS; l++) init[(size_t)l * POA_LIST_STRIDE] = (unsigned long long)POA_NIL;
-        return hipMemcpy(d_head.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
+        const hipError_t e = hipMemcpy(d_head.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
+        return e != hipSuccess ? e : hipStreamSynchronize(nullptr);  // (the copy is on the device before anything is launched: see d_slot_flag)
     }
     // vga_align_prepare: the state regions and the first segments, allocated on a thread of its own before the first
     // vga_align_batch call needs them (on memory another process used the driver clears what it hands out: 13 GB = 0.2 s)
@@ -543,7 +560,6 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     // what this context may take of the GPU: everything else it allocates (staging of three sub-batches, the subgraph store,
     // the map workspace) keeps 15 % of what is free, at least 16 GB -- two processes sharing a GPU otherwise starve each other
     uint64_t avail_pool = 0;
-    double gpu_share = 1.0;  // (contexts that share the GPU: this one's part of its memory and of the resident workgroups)
     {
         size_t free_b = 0, total_b = 0;
         POA_CHECK(hipMemGetInfo(&free_b, &total_b));
@@ -556,7 +572,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         {
             double f = ctx->pool_fraction;
             if (const char *fr = getenv("VGA_POOL_FRACTION")) f = atof(fr);
-            if (f > 0.0 && f < 1.0) { avail_pool = (uint64_t)((double)avail_pool * f); gpu_share = f; }
+            if (f > 0.0 && f < 1.0) avail_pool = (uint64_t)((double)avail_pool * f);
         }
         if (const char *env_pool = getenv("VGA_POOL_BYTES")) avail_pool = std::min<uint64_t>(avail_pool, strtoull(env_pool, nullptr, 10));
     }
@@ -613,7 +629,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         uint64_t ns = std::min<uint64_t>(16ull * (uint64_t)ctx->n_cu, std::max<uint64_t>(n, 64));  // (16 two-wave workgroups per CU at most)
         if (const char *e = getenv("VGA_POA_ARENAS")) ns = std::min<uint64_t>(ns, std::max<uint64_t>(1, strtoull(e, nullptr, 10)));
         while (ns > 1 && ns * state_size > avail_pool / 4) ns /= 2;
-        const uint64_t resident = std::min<uint64_t>(n, std::max<uint64_t>(32, (uint64_t)(6.0 * (double)ctx->n_cu * gpu_share)));
+        // (not scaled by the context's share of the GPU: a context whose slice holds a call's longest problems needs their whole
+        // footprint whatever its share -- scaled, eight contexts on one GPU waited seconds for chunks and gave problems up)
+        const uint64_t resident = std::min<uint64_t>(n, 6ull * (uint64_t)ctx->n_cu);
         double fill = 0.7;
         if (const char *e = getenv("VGA_POOL_FILL")) fill = atof(e);
         uint64_t want = (uint64_t)((double)resident * probe_mean * W.pool_scale * fill) + 64 * POA_CHUNK;
@@ -654,12 +672,25 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                     POA_CHECK(hipStreamCreateWithFlags(&W.add_stream, hipStreamNonBlocking));
                     POA_CHECK(W.reset_lists());
                 }
-                POA_CHECK(hipMemset(W.d_slot_flag.p, 0, ns * sizeof(uint32_t)));
+                // (on the context's stream, and waited for: hipMemset runs on the null stream and may return before the device has
+                // done it -- no stream of this library waits for the null stream, and on a GPU that other contexts keep full the
+                // flags were cleared AFTER the first workgroups of slots 1 and 2 had taken their state regions: a second workgroup
+                // took the same region, and both problems came back with wrong alignments)
+                POA_CHECK(hipMemsetAsync(W.d_slot_flag.p, 0, ns * sizeof(uint32_t), st));
+                POA_CHECK(hipStreamSynchronize(st));
                 n_arenas = (uint32_t)ns;
                 CP.head = W.d_head.p; CP.next = W.d_next_chunk.p; CP.seg_base = W.d_seg_base.p;
                 CP.cps_log2 = POA_SEG_LOG2 - 20; CP.n_slots = n_arenas; CP.state_base = W.state; CP.state_size = state_size;
                 CP.slot_flag = W.d_slot_flag.p; CP.stats = W.d_head.p + POA_LISTS * POA_LIST_STRIDE;
                 CP.short_flag = W.h_short.p;
+                if (getenv("VGA_POOL_CHECK") && atoi(getenv("VGA_POOL_CHECK")) != 0) {  // (diagnostics: vga_poa_kernels.hpp, poa_chunk_pool::owner)
+                    if (!W.d_owner.p) {
+                        POA_CHECK(W.d_owner.reserve(max_chunks));
+                        POA_CHECK(hipMemsetAsync(W.d_owner.p, 0, W.d_owner.cap * sizeof(uint32_t), st));
+                        POA_CHECK(hipStreamSynchronize(st));
+                    }
+                    CP.owner = W.d_owner.p;
+                }
             }
         }
     }
@@ -1009,23 +1040,24 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
 #define POA_T4_LAUNCH(T)                                                                                                     \
     case T:                                                                                                                  \
         if (t5 && def_pen) {                                                                                                 \
-            chk(hipFuncSetAttribute((const void *)k_poa_dp_t5<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            chk(poa_allow_lds(ctx->device, (const void *)k_poa_dp_t5<T, true>, lds)); \
             hipLaunchKernelGGL((k_poa_dp_t5<T, true>), dim3(nb), dim3(T), lds, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t5a);                                    \
         } else if (t5) {                                                                                                     \
-            chk(hipFuncSetAttribute((const void *)k_poa_dp_t5<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            chk(poa_allow_lds(ctx->device, (const void *)k_poa_dp_t5<T, false>, lds)); \
             hipLaunchKernelGGL((k_poa_dp_t5<T, false>), dim3(nb), dim3(T), lds, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t5a);                                   \
         } else if (def_pen) {                                                                                                     \
-            chk(hipFuncSetAttribute((const void *)k_poa_dp_t4<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            chk(poa_allow_lds(ctx->device, (const void *)k_poa_dp_t4<T, true>, lds)); \
             hipLaunchKernelGGL((k_poa_dp_t4<T, true>), dim3(nb), dim3(T), lds, st, POA_T4_ARGS);                            \
         } else {                                                                                                             \
-            chk(hipFuncSetAttribute((const void *)k_poa_dp_t4<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            chk(poa_allow_lds(ctx->device, (const void *)k_poa_dp_t4<T, false>, lds)); \
             hipLaunchKernelGGL((k_poa_dp_t4<T, false>), dim3(nb), dim3(T), lds, st, POA_T4_ARGS);                           \
         }                                                                                                                    \
         break;
                 // k_poa_dp_t6 (vga_poa_t6.hpp): one wave per problem, the row in registers -- launches of narrow bands in chunk-pool
                 // mode with the fused traceback; what does not fit its window comes back with POA_ST_RETRY and runs below
                 const bool t6_forced = force && strstr(force, "t6");
-                const bool t6 = t5 && arena && sub_fused && !general && !giant && !(force && strstr(force, "t5")) && (t6_forced || (mean_w <= 800.0 && mw <= 1000.0));
+                const bool t6 = t5 && arena && sub_fused && !general && !giant && !(force && strstr(force, "t5")) && !(getenv("VGA_POA_T6") && atoi(getenv("VGA_POA_T6")) == 0) &&
+                                (t6_forced || (mean_w <= 800.0 && mw <= 1000.0));
                 // k_poa_dp_t7 (vga_poa_t7.hpp): t6's eight-columns-per-lane row for bands that need several waves.  The launch of a call's
                 // longest problems runs it (1 024 threads: 8 192 columns per step, every column in LDS): their rows are a serial chain
                 // on a CU of their own, and a t7 row takes 4.9-5.9 us where a t5 row of the same 6 000-column band takes 7.6 (config 4:
@@ -1048,10 +1080,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
 #define POA_T7_LAUNCH(T)                                                                                                         \
     case T:                                                                                                                      \
         if (def_pen) {                                                                                                           \
-            chk(hipFuncSetAttribute((const void *)k_poa_dp_t7<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7)); \
+            chk(poa_allow_lds(ctx->device, (const void *)k_poa_dp_t7<T, true>, lds7)); \
             hipLaunchKernelGGL((k_poa_dp_t7<T, true>), dim3(nb), dim3(T), lds7, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t7a); \
         } else {                                                                                                                 \
-            chk(hipFuncSetAttribute((const void *)k_poa_dp_t7<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds7)); \
+            chk(poa_allow_lds(ctx->device, (const void *)k_poa_dp_t7<T, false>, lds7)); \
             hipLaunchKernelGGL((k_poa_dp_t7<T, false>), dim3(nb), dim3(T), lds7, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t7a); \
         }                                                                                                                        \
         break;
@@ -1064,10 +1096,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                     const size_t lds6 = poa_t6_lds_bytes<8>(lds_cols);
                     if (tr.on) fprintf(stderr, "[vga-trace] poa:     k_poa_dp_t6<8>: one wave per problem, LDS %zu B\n", lds6);
                     if (def_pen) {
-                        chk(hipFuncSetAttribute((const void *)k_poa_dp_t6<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6));
+                        chk(poa_allow_lds(ctx->device, (const void *)k_poa_dp_t6<8, true>, lds6));
                         hipLaunchKernelGGL((k_poa_dp_t6<8, true>), dim3(nb), dim3(64), lds6, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t5a);
                     } else {
-                        chk(hipFuncSetAttribute((const void *)k_poa_dp_t6<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6));
+                        chk(poa_allow_lds(ctx->device, (const void *)k_poa_dp_t6<8, false>, lds6));
                         hipLaunchKernelGGL((k_poa_dp_t6<8, false>), dim3(nb), dim3(64), lds6, st, S.d_probs.p, S.d_q.p, S.d_ntab.p, S.d_seq32.p, S.d_preds.p, t5a);
                     }
                 } else
@@ -1079,13 +1111,13 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
 #undef POA_T4_LAUNCH
 #undef POA_T4_ARGS
             } else if (nt == 128) {
-                chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                chk(poa_allow_lds(ctx->device, (const void *)k_poa_dp_lds<128, 4>, lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<128, 4>), dim3(nb), dim3(128), lds, st, POA_ARGS);
             } else if (nt == 256) {
-                chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<256, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                chk(poa_allow_lds(ctx->device, (const void *)k_poa_dp_lds<256, 4>, lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<256, 4>), dim3(nb), dim3(256), lds, st, POA_ARGS);
             } else {
-                chk(hipFuncSetAttribute((const void *)k_poa_dp_lds<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                chk(poa_allow_lds(ctx->device, (const void *)k_poa_dp_lds<512, 4>, lds));
                 hipLaunchKernelGGL((k_poa_dp_lds<512, 4>), dim3(nb), dim3(512), lds, st, POA_ARGS);
             }
 #undef POA_ARGS
@@ -1479,6 +1511,14 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     if (dev_failed) return dev_rc;  // (sg_prepare_rest has set the message)
     vga_timer_end(ctx, t_total);
     tr.mark("dp + traceback + cigar (pipelined sub-batches)");
+    if (n_arenas && CP.owner) {
+        unsigned long long bad[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(bad, CP.stats + 4, sizeof bad, hipMemcpyDeviceToHost);
+        if (bad[0] || bad[1])
+            return vga_set_error(ctx, VGA_ERR_HIP, "chunk pool check: %llu chunks were handed out while somebody held them, %llu (+ %llu broken chains) came back from somebody else "
+                                 "(the first: chunk %llu held by %llu, pushed by %llu, position %llu of its chain, %llu threads)",
+                                 bad[0], bad[1] & 0xFFFFFFFFull, bad[1] >> 32, bad[2] & 0xFFFFFFFFull, bad[2] >> 32, bad[3] & 0xFFFFFFFFull, (bad[3] >> 32) & 0xFFFFull, bad[3] >> 48);
+    }
     if (tr.on && n_arenas) {
         unsigned long long empties = 0;
         (void)hipMemcpy(&empties, W.d_head.p + POA_LISTS * POA_LIST_STRIDE, sizeof empties, hipMemcpyDeviceToHost);

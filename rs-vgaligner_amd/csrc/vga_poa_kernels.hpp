@@ -118,6 +118,8 @@ struct poa_chunk_pool {
     uint64_t state_size;
     uint32_t *slot_flag;         // 0 free / 1 taken
     unsigned long long *stats;   // [0] requests that found every list empty (the host adds segments when it grows)
+    uint32_t *owner;             // VGA_POOL_CHECK=1 (diagnostics, else null): per chunk, who holds it (0: a free list) -- a chunk popped while
+                                 // held, or pushed by somebody else, counts in stats[4] / stats[5] and fails the call
     uint32_t *short_flag;        // pinned host memory: set to 1 with stats[0] -- the host's keeper thread reads (and clears) it
                                  // without any GPU work of its own (a copy of stats[0] waited 0.1-0.2 s for a slot on a full GPU)
 };
@@ -140,7 +142,10 @@ __device__ __forceinline__ uint32_t poa_chunk_pop(const poa_chunk_pool &C, uint3
                 const uint32_t idx = (uint32_t)h;
                 if (idx == POA_NIL) break;
                 const uint32_t nx = __hip_atomic_load(C.next + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (atomicCAS(hd, h, ((h >> 32) + 1ull) << 32 | nx) == h) return idx;
+                if (atomicCAS(hd, h, ((h >> 32) + 1ull) << 32 | nx) == h) {
+                    if (C.owner && atomicExch(&C.owner[idx], home + 1u) != 0u) (void)atomicAdd(C.stats + 4, 1ull);
+                    return idx;
+                }
             }
         }
         if (round == 0) {
@@ -152,8 +157,20 @@ __device__ __forceinline__ uint32_t poa_chunk_pop(const poa_chunk_pool &C, uint3
     return POA_NIL;
 }
 // one thread: push the list first -> ... -> last (linked through C.next) onto free list `home` in one step
-__device__ __forceinline__ void poa_chunk_push(const poa_chunk_pool &C, uint32_t home, uint32_t first, uint32_t last)
+__device__ __forceinline__ void poa_chunk_push(const poa_chunk_pool &C, uint32_t home, uint32_t first, uint32_t last, bool held = true)
 {
+    if (C.owner && held)
+        for (uint32_t c = first, guard = 0; guard < (1u << 20); guard++) {
+            const uint32_t was = atomicExch(&C.owner[c], 0u);
+            if (was != home + 1u) {
+                (void)atomicAdd(C.stats + 5, 1ull);
+                if (atomicCAS(C.stats + 6, 0ull, (unsigned long long)was << 32 | c) == 0ull)
+                    (void)atomicExch(C.stats + 7, (unsigned long long)blockDim.x << 48 | (unsigned long long)guard << 32 | (home + 1u));
+            }
+            if (c == last) break;
+            c = __hip_atomic_load(C.next + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c == POA_NIL) { (void)atomicAdd(C.stats + 5, 1ull << 32); break; }
+        }
     unsigned long long *hd = C.head + (size_t)(home % POA_LISTS) * POA_LIST_STRIDE;
     for (;;) {
         unsigned long long h = __hip_atomic_load(hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -169,7 +186,7 @@ __global__ void k_poa_chunks_add(poa_chunk_pool C, uint32_t first, uint32_t coun
     if (blockIdx.x != 0 || l >= POA_LISTS || l >= count) return;
     uint32_t last = first + l;
     for (uint32_t i = first + l; i + POA_LISTS < first + count; i += POA_LISTS) { C.next[i] = i + POA_LISTS; last = i + POA_LISTS; }
-    poa_chunk_push(C, l, first + l, last);
+    poa_chunk_push(C, l, first + l, last, false);
 }
 __device__ __forceinline__ int poa_slot_acquire(uint32_t *flag, uint32_t n, uint32_t block)
 {

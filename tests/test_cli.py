@@ -13,8 +13,8 @@ EXE = os.path.join(ROOT, "rs-vgaligner_amd", "vgaligner")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-def run(args, cwd, ok=True):
-    p = subprocess.run([EXE] + args, cwd=cwd, capture_output=True, text=True, timeout=600)
+def run(args, cwd, ok=True, env=None):
+    p = subprocess.run([EXE] + args, cwd=cwd, capture_output=True, text=True, timeout=600, env=None if env is None else dict(os.environ, **env))
     assert (p.returncode == 0) == ok, p.stderr
     return p
 
@@ -188,7 +188,10 @@ def test_cli_eight_contexts_on_one_gpu_rehearse_an_eight_gpu_node(tmp_path, conf
     t0 = time.perf_counter()
     one = run(base + ["-o", os.path.join(d, "one"), "--device", "0", "--chunk-reads", "0"], d)
     t1 = time.perf_counter()
-    eight = run(base + ["-o", os.path.join(d, "eight"), "--devices", "0,0,0,0,0,0,0,0", "--chunk-reads", "1500"], d)
+    # VGA_POOL_CHECK=1: every chunk of the traceback pool carries its holder, and a chunk that is handed out while held (or
+    # comes back from somebody else) fails the call -- the diagnostic that found the state-region flags being cleared late
+    # on a busy GPU (round 4's wrong alignments with eight contexts)
+    eight = run(base + ["-o", os.path.join(d, "eight"), "--devices", "0,0,0,0,0,0,0,0", "--chunk-reads", "1500"], d, env={"VGA_POOL_CHECK": "1"})
     t2 = time.perf_counter()
     print("one context %.2f s, eight contexts %.2f s" % (t1 - t0, t2 - t1))
     import re
