@@ -386,7 +386,11 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         {
             double wsum = 0;
             for (uint64_t i = 0; i < n; i++) wsum += west[i];
-            if (n && wsum / (double)n <= 700.0) split = n;  // (config 5: 650-660; config 3: 1 500-2 500; config 4: in between and above)
+            // (config 5: 650-740 from chunk to chunk; config 3: 1 500-2 500; config 4: in between and above)
+            if (n && wsum / (double)n <= 900.0) split = n;
+            if (getenv("VGA_TRACE") && atoi(getenv("VGA_TRACE")) != 0)
+                fprintf(stderr, "[vga-trace] align: mean width term of the launch-order proxy %.0f: the subgraph store is built in %s\n", n ? wsum / (double)n : 0.0,
+                        split == n ? "one part" : "two parts");
         }
         if (const char *e = getenv("VGA_SG_SPLIT")) { const long v = atol(e); split = v <= 0 ? n : std::min<uint64_t>(n, (uint64_t)v); }  // (0: one part)
         const int rc = sg_prepare(ctx, descs.data(), q_src.data(), n, split, b->d_reads, params->remain_rule, store);

@@ -247,28 +247,37 @@ __device__ __forceinline__ double vga_wave_max_f64_to_lane63(double v)
     return v;
 }
 
-template <bool GAP_LDS>
-__global__ __launch_bounds__(256) void k_chain4(
-    uint32_t R, const uint64_t *__restrict__ anchor_off, const uint32_t *__restrict__ s_id, const uint32_t *__restrict__ s_qb,
-    const uint32_t *__restrict__ s_tb, const uint32_t *__restrict__ s_te, uint32_t k, uint32_t bandwidth,
-    uint64_t max_gap, uint32_t min_anchors, const double *__restrict__ gap_cost, double *__restrict__ f_out,
-    int32_t *__restrict__ pred_id_out, int32_t *pred_pos, double *__restrict__ curr_max_out,
-    uint32_t *__restrict__ chain_buf, uint32_t *__restrict__ chain_cnt, uint32_t *__restrict__ chain_words)
+__device__ __forceinline__ int vga_wave_max_i32_to_lane63(int v)
 {
-    extern __shared__ __attribute__((aligned(16))) double s_gap[];
-    if constexpr (GAP_LDS) {
-        for (uint64_t g = threadIdx.x; g <= max_gap; g += blockDim.x) s_gap[g] = gap_cost[g];
-        __syncthreads();
+#define VGA_STAGE(ctrl, rmask)                                                                                    \
+    {                                                                                                             \
+        const int t = __builtin_amdgcn_update_dpp(INT32_MIN, v, ctrl, rmask, 0xf, false);                         \
+        v = t > v ? t : v;                                                                                        \
     }
-    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= R) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t a0 = anchor_off[r];
-    const uint32_t A = (uint32_t)(anchor_off[r + 1] - a0);
+    VGA_STAGE(0x111, 0xf)
+    VGA_STAGE(0x112, 0xf)
+    VGA_STAGE(0x114, 0xf)
+    VGA_STAGE(0x118, 0xf)
+    VGA_STAGE(0x142, 0xa)
+    VGA_STAGE(0x143, 0xc)
+#undef VGA_STAGE
+    return v;
+}
+
+// The scores of a step's candidates are round(1000 s) / 1000 (src/chain.rs:362-366): the argmax runs on the integers round(1000 s)
+// when every score of the read is known to fit 32 bits (IKEY: k (A + 2) + gap_cost[max_gap] < 2^31 / 1000, decided per read from
+// key_anchors) -- six v_max_i32_dpp instead of six stages of two DPP moves, an f64 compare and two selects, and the division by
+// 1000 once per step, for the winner.  x -> x / 1000 is strictly increasing on these integers (neighbours are 10^-3 apart, an ulp
+// is below 10^-9), so the maximum, the lanes that hold it and f(i) = max / 1000 + 0.0 are what the f64 reduction gives, bit for bit.
+template <bool GAP_LDS, bool IKEY>
+__device__ __forceinline__ void vga_chain_dp(uint32_t lane, uint64_t a0, uint32_t A, const uint32_t *__restrict__ s_id,
+                                             const uint32_t *__restrict__ s_qb, const uint32_t *__restrict__ s_tb,
+                                             const uint32_t *__restrict__ s_te, uint32_t k, uint32_t bandwidth, uint64_t max_gap,
+                                             const double *__restrict__ gap_cost, const double *s_gap, double *__restrict__ f_out,
+                                             int32_t *__restrict__ pred_id_out, int32_t *pred_pos, double &curr_max)
+{
     const double kd = (double)k;
     const double NEGMAX = -1.7976931348623157e308;  // -f64::MAX
-    double curr_max = 0.0;
-
     double f_l = 0.0;
     uint32_t qb_l = 0, tb_l = 0, te_l = 0;
     int j_l = -1, pj_l = -1;
@@ -283,6 +292,7 @@ __global__ __launch_bounds__(256) void k_chain4(
             const uint32_t tbi = (uint32_t)__builtin_amdgcn_readlane((int)ct, (int)ii);
             const uint32_t tei = (uint32_t)__builtin_amdgcn_readlane((int)ce, (int)ii);
             double p = NEGMAX;
+            int key = INT32_MIN;  // (IKEY) round(1000 s) of this lane's candidate; no real score reaches INT32_MIN
             int j = -1;
             if (i > 0) {
                 const int min_j = (bandwidth > i) ? 0 : (int)(i - bandwidth);  // src/chain.rs:404-407
@@ -306,20 +316,38 @@ __global__ __launch_bounds__(256) void k_chain4(
                             s = s - gc;
                             s = s * 1000.0;
                             s = round(s);
-                            s = s / 1000.0;
-                            s = s + 0.0;
-                            p = s;
+                            if constexpr (IKEY) key = (int)s;
+                            else {
+                                s = s / 1000.0;
+                                s = s + 0.0;
+                                p = s;
+                            }
                             ok = true;
                         }
                     }
                 }
                 // the maximum, then the largest j among the lanes that hold it (src/chain.rs:417,430: the scan runs from
                 // i-1 downwards with a strict '>')
-                const double red = vga_wave_max_f64_to_lane63(p);
-                const double pmax = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(red), 63),
-                                                     __builtin_amdgcn_readlane(__double2loint(red), 63));
-                const uint64_t mask = __ballot(ok && p == pmax);
-                p = pmax;
+                uint64_t mask;
+                if constexpr (IKEY) {
+                    const int kmax = __builtin_amdgcn_readlane(vga_wave_max_i32_to_lane63(key), 63);
+                    mask = kmax != INT32_MIN ? __ballot(key == kmax) : 0ull;
+                    // kmax / 1000.0 without the division sequence (v_rcp_f64 and ten more): q = x c, r = fma(-q, 1000, x), q + r c
+                    // with c = 1 / 1000 is the correctly rounded quotient for EVERY 32-bit integer x -- checked exhaustively on the
+                    // host (tests/test_chain_arith_cpu.py runs the check)
+                    {
+                        const double x = (double)kmax, c = 1.0 / 1000.0;
+                        const double q = x * c;
+                        const double r = __builtin_fma(-q, 1000.0, x);
+                        p = __builtin_fma(r, c, q) + 0.0;
+                    }
+                } else {
+                    const double red = vga_wave_max_f64_to_lane63(p);
+                    const double pmax = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(red), 63),
+                                                         __builtin_amdgcn_readlane(__double2loint(red), 63));
+                    mask = __ballot(ok && p == pmax);
+                    p = pmax;
+                }
                 if (mask) {
                     const uint32_t sft = 63u - ((i - 1u) & 63u);  // lane (i-1) & 63 -> bit 63
                     const uint64_t rot = sft ? ((mask << sft) | (mask >> (64u - sft))) : mask;
@@ -340,6 +368,31 @@ __global__ __launch_bounds__(256) void k_chain4(
             pred_id_out[a0 + base + lane] = pj_l >= 0 ? (int32_t)s_id[a0 + pj_l] : -1;
         }
     }
+}
+
+template <bool GAP_LDS>
+__global__ __launch_bounds__(256) void k_chain4(
+    uint32_t R, const uint64_t *__restrict__ anchor_off, const uint32_t *__restrict__ s_id, const uint32_t *__restrict__ s_qb,
+    const uint32_t *__restrict__ s_tb, const uint32_t *__restrict__ s_te, uint32_t k, uint32_t bandwidth,
+    uint64_t max_gap, uint32_t min_anchors, const double *__restrict__ gap_cost, double *__restrict__ f_out,
+    int32_t *__restrict__ pred_id_out, int32_t *pred_pos, double *__restrict__ curr_max_out,
+    uint32_t *__restrict__ chain_buf, uint32_t *__restrict__ chain_cnt, uint32_t *__restrict__ chain_words, uint32_t key_anchors)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_gap[];
+    if constexpr (GAP_LDS) {
+        for (uint64_t g = threadIdx.x; g <= max_gap; g += blockDim.x) s_gap[g] = gap_cost[g];
+        __syncthreads();
+    }
+    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t a0 = anchor_off[r];
+    const uint32_t A = (uint32_t)(anchor_off[r + 1] - a0);
+    double curr_max = 0.0;
+    if (A <= key_anchors)
+        vga_chain_dp<GAP_LDS, true>(lane, a0, A, s_id, s_qb, s_tb, s_te, k, bandwidth, max_gap, gap_cost, s_gap, f_out, pred_id_out, pred_pos, curr_max);
+    else
+        vga_chain_dp<GAP_LDS, false>(lane, a0, A, s_id, s_qb, s_tb, s_te, k, bandwidth, max_gap, gap_cost, s_gap, f_out, pred_id_out, pred_pos, curr_max);
     if (lane == 0) curr_max_out[r] = curr_max;
     __threadfence_block();
 
@@ -594,9 +647,16 @@ static int vga_map_batch_impl(vga_batch *b, const vga_map_params *params, vga_ma
     int t4 = vga_timer_begin(ctx, "chain_dp", 16 * total + 12 * total);
     {
         const size_t gap_bytes = (size_t)(params->max_gap + 1) * sizeof(double);
+        // reads with at most this many anchors take their argmax on round(1000 score) as a 32-bit integer (vga_chain_dp):
+        // |score| <= k (A + 1) + gap_cost[max_gap], with room to spare
+        uint32_t key_anchors = 0;
+        {
+            const double room = 2147483647.0 / 1000.0 - gc[mg] - 4.0 * (double)ix.k - 16.0;
+            if (room > 0.0 && !getenv("VGA_CHAIN_F64")) key_anchors = (uint32_t)std::min(room / (double)ix.k, 4.0e9);
+        }
 #define CHAIN_ARGS ws.anchor_off.p, perm, ws.s_qb.p, ws.s_tb.p, ws.s_te.p, ix.k, params->bandwidth, params->max_gap,           \
                    params->chain_min_n_anchors, ws.gap_cost.p, ws.f.p, ws.pred_id.p, ws.pred_pos.p, ws.curr_max.p,         \
-                   ws.chain_buf.p, ws.chain_cnt.p, ws.chain_words.p
+                   ws.chain_buf.p, ws.chain_cnt.p, ws.chain_words.p, key_anchors
         if (gap_bytes <= 16 * 1024)  // (8 KB at the default max_gap; bigger tables stay in HBM)
             hipLaunchKernelGGL(k_chain4<true>, dim3((unsigned)((R + 3) / 4)), dim3(256), gap_bytes, st, (uint32_t)R, CHAIN_ARGS);
         else
