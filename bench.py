@@ -123,6 +123,8 @@ def main():
     if args.remain_rule is None:
         args.remain_rule = int(poa_params.remain_rule)
     poa_params.remain_rule = args.remain_rule
+    if os.environ.get("VGA_BENCH_WF"):  # (diagnostics only: another band -- not the workload BASELINE.json names; the line says so)
+        poa_params.wf = float(os.environ["VGA_BENCH_WF"])
     step = batch.map_raw if map_only else (lambda: batch.map_align_raw(poa_params=poa_params))
     for _ in range(args.warmup):
         last = step()
@@ -321,7 +323,8 @@ def main():
         "config": {"workload": "%s, k=11, %d x %d bp %s reads per GPU%s"
                                % (wl_name, args.reads, args.read_len, "1 %-substitution" if map_only else "ONT-profile", "" if map_only else ", --also-align"),
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "sharding": "reads, replicated index, no collective",
-                   "poa_remain_rule": ["longest-path", "first-out-edge"][args.remain_rule]},
+                   "poa_remain_rule": ["longest-path", "first-out-edge"][args.remain_rule],
+                   **({"diagnostic_band_wf": float(os.environ["VGA_BENCH_WF"])} if os.environ.get("VGA_BENCH_WF") and not map_only else {})},
         "roofline": roofline,
         "other_remain_rule": other_rule,
         "cpu_baseline": cpu,

@@ -398,6 +398,7 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         sub_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
         feed.dev = &store;
         feed.want_rows = false;  // (this caller reads the deduplicated path, its length and the strings: k_poa_text may write them)
+        feed.keep_text = true;   // ... and copies each string once, from where it came back (poa_item::cs_p) into the result below
         // The rows of the first part's problems are known now.  Very long ones (config 3's longest have 21 000 rows; a chain
         // that spans 100 kbp of the linearisation has 110 000, all sequential) decide how long the call takes: they go
         // first, in a launch of their own with 512 threads and an 8 192-column window (poa_run).  The order inside the
@@ -478,9 +479,11 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         pick[r] = best;
         if (best >= 0) {
             // graph_nodes.dedup() (align.rs:1114): count the runs
-            const std::vector<uint32_t> &gn = items[best].gnodes;
+            const poa_item &ib = items[best];
+            const uint32_t *gn = ib.gnodes_p ? ib.gnodes_p : ib.gnodes.data();
+            const size_t gnn = ib.gnodes_p ? ib.gnodes_n : ib.gnodes.size();
             uint32_t c = 0;
-            for (size_t t = 0; t < gn.size(); t++) c += (t == 0 || gn[t] != gn[t - 1]);
+            for (size_t t = 0; t < gnn; t++) c += (t == 0 || gn[t] != gn[t - 1]);
             path_n[r] = c;
         }
     });
@@ -488,8 +491,8 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     for (uint64_t r = 0; r < R; r++) {
         res->path_off[r] = tp; res->cigar_off[r] = tc; res->cs_off[r] = ts;
         tp += path_n[r];
-        tc += pick[r] >= 0 ? items[pick[r]].cigar.size() + 1 : 1;
-        ts += pick[r] >= 0 ? items[pick[r]].cs.size() + 1 : 1;
+        tc += pick[r] >= 0 ? (items[pick[r]].cs_p ? items[pick[r]].cigar_n : items[pick[r]].cigar.size()) + 1 : 1;
+        ts += pick[r] >= 0 ? (items[pick[r]].cs_p ? items[pick[r]].cs_n : items[pick[r]].cs.size()) + 1 : 1;
     }
     res->path_off[R] = tp; res->cigar_off[R] = tc; res->cs_off[R] = ts;
     res->path_handles = amalloc<uint64_t>(tp);
@@ -508,16 +511,23 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         const uint64_t p = (uint64_t)pick[r];
         const poa_item &it = items[p];
         uint64_t o = res->path_off[r];
-        for (size_t t = 0; t < it.gnodes.size(); t++)
-            if (t == 0 || it.gnodes[t] != it.gnodes[t - 1])  // align.rs:1120-1123
-                res->path_handles[o++] = on_device ? store.of(p).h_handles[store.off[p].node0 + it.gnodes[t]] : SG[p].handles[it.gnodes[t]];
+        const uint32_t *gn = it.gnodes_p ? it.gnodes_p : it.gnodes.data();
+        const size_t gnn = it.gnodes_p ? it.gnodes_n : it.gnodes.size();
+        for (size_t t = 0; t < gnn; t++)
+            if (t == 0 || gn[t] != gn[t - 1])  // align.rs:1120-1123
+                res->path_handles[o++] = on_device ? store.of(p).h_handles[store.off[p].node0 + gn[t]] : SG[p].handles[gn[t]];
         res->path_length[r] = it.n_path;
         res->path_start[r] = it.start_off;
         res->path_end[r] = it.end_off;
         res->block_length[r] = it.aligned;
         res->best_score[r] = it.score;
-        memcpy(res->cigar + res->cigar_off[r], it.cigar.c_str(), it.cigar.size() + 1);
-        memcpy(res->cs + res->cs_off[r], it.cs.c_str(), it.cs.size() + 1);
+        if (it.cs_p) {  // (device text, where it came back: the one copy of the strings on the host)
+            memcpy(res->cigar + res->cigar_off[r], it.cigar_p, it.cigar_n); res->cigar[res->cigar_off[r] + it.cigar_n] = 0;
+            memcpy(res->cs + res->cs_off[r], it.cs_p, it.cs_n); res->cs[res->cs_off[r] + it.cs_n] = 0;
+        } else {
+            memcpy(res->cigar + res->cigar_off[r], it.cigar.c_str(), it.cigar.size() + 1);
+            memcpy(res->cs + res->cs_off[r], it.cs.c_str(), it.cs.size() + 1);
+        }
     });
     res->poa_problems = n;
     for (uint64_t p = 0; p < n; p++) {

@@ -33,6 +33,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -210,6 +211,7 @@ struct poa_slot {
         vga_hbuf<char> h_seq;     // device store: the bases of the sub-batch's problems (row r of a problem is byte seq0 + r - 1)
         vga_hbuf<poa_out> h_outs;
         vga_hbuf<char> h_text;
+        char *text_p = nullptr;  // where this launch's text is: h_text.p, or a buffer of poa_ws::text_live (poa_feed::keep_text)
         vga_hbuf<poa_text_out> h_touts;
         vga_hbuf<unsigned long long> h_tcur;
         bool text = false;        // this sub-batch's strings were written on the device
@@ -257,6 +259,8 @@ struct poa_ws {
     size_t segs_listed = 0;
     uint8_t *state = nullptr;             // the state regions
     uint64_t state_bytes = 0;
+    // poa_feed::keep_text: the text of every launch of a call in a pinned buffer of its own, alive until the next call
+    std::vector<std::unique_ptr<vga_hbuf<char>>> text_live, text_free;
     hipError_t reset_lists()  // every free list empty, statistics zero
     {
         std::vector<unsigned long long> init(POA_LISTS * POA_LIST_STRIDE + 16, 0ull);
@@ -539,6 +543,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         ctx->poa_ws_free = [](void *q) { delete (poa_ws *)q; };
     }
     poa_ws &W = *(poa_ws *)ctx->poa_ws;
+    // (poa_feed::keep_text: what the previous call's items pointed into has been read by now)
+    for (auto &hb : W.text_live) W.text_free.push_back(std::move(hb));
+    W.text_live.clear();
     W.join_preparer();
 #define POA_CHECK(call)                                                                              \
     do {                                                                                             \
@@ -1183,10 +1190,17 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         if (S.text && S.h_touts.p[i - i0].flags == 1u) {
             // K4c wrote the fields (vga_poa_text.hpp): they are copied, not derived
             const poa_text_out &t = S.h_touts.p[i - i0];
-            it.cs.assign(S.h_text.p + t.cs_off, t.cs_len);
-            it.cigar.assign(S.h_text.p + t.cg_off, t.cg_len);
-            const uint32_t *runs = (const uint32_t *)(S.h_text.p + t.runs_off);
-            it.gnodes.assign(runs, runs + t.n_runs);
+            const uint32_t *runs = (const uint32_t *)(S.text_p + t.runs_off);
+            if (feed.keep_text) {
+                it.cs_p = S.text_p + t.cs_off; it.cs_n = t.cs_len;
+                it.cigar_p = S.text_p + t.cg_off; it.cigar_n = t.cg_len;
+                it.gnodes_p = runs; it.gnodes_n = t.n_runs;
+                it.cs.clear(); it.cigar.clear(); it.gnodes.clear();
+            } else {
+                it.cs.assign(S.text_p + t.cs_off, t.cs_len);
+                it.cigar.assign(S.text_p + t.cg_off, t.cg_len);
+                it.gnodes.assign(runs, runs + t.n_runs);
+            }
             it.rows.clear();
             it.deduped = true;
             it.n_path = t.n_path; it.start_off = t.start_off; it.end_off = t.end_off; it.aligned = t.aligned;
@@ -1343,17 +1357,35 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
             const uint64_t used = std::min<uint64_t>(S.h_tcur.p[0], SL.d_text.cap);
             bool overflow = false;
             for (uint64_t i = cur.i0; i < cur.i1; i++) overflow = overflow || S.h_touts.p[i - cur.i0].flags == 2u;
-            hipError_t ce = S.h_text.reserve(used + 16);
+            hipError_t ce = hipSuccess;
+            if (feed.keep_text) {
+                // a buffer of the context's that holds the text: the smallest free one that fits, else the largest free one grows
+                size_t pickb = W.text_free.size(), big = W.text_free.size();
+                for (size_t k = 0; k < W.text_free.size(); k++) {
+                    if (W.text_free[k]->cap >= used + 16 && (pickb == W.text_free.size() || W.text_free[k]->cap < W.text_free[pickb]->cap)) pickb = k;
+                    if (big == W.text_free.size() || W.text_free[k]->cap > W.text_free[big]->cap) big = k;
+                }
+                if (pickb == W.text_free.size()) pickb = big;
+                std::unique_ptr<vga_hbuf<char>> hb;
+                if (pickb < W.text_free.size()) { hb = std::move(W.text_free[pickb]); W.text_free.erase(W.text_free.begin() + (long)pickb); }
+                else hb.reset(new vga_hbuf<char>());
+                ce = hb->reserve(used + 16);
+                S.text_p = hb->p;
+                W.text_live.push_back(std::move(hb));
+            } else {
+                ce = S.h_text.reserve(used + 16);
+                S.text_p = S.h_text.p;
+            }
             if (ce == hipSuccess && used) {
                 void *hd = nullptr;
-                if (!getenv("VGA_POA_TEXT_MEMCPY") && hipHostGetDevicePointer(&hd, S.h_text.p, 0) == hipSuccess && hd) {
+                if (!getenv("VGA_POA_TEXT_MEMCPY") && hipHostGetDevicePointer(&hd, S.text_p, 0) == hipSuccess && hd) {
                     const uint64_t n16 = (used + 15) / 16;  // (both buffers are 16-byte aligned and hold 16 bytes of slack)
                     hipLaunchKernelGGL(k_poa_text_to_host, dim3((unsigned)std::min<uint64_t>(256, (n16 + 255) / 256)), dim3(256), 0, sarr[cur.slot],
                                        (const uint4 *)SL.d_text.p, (uint4 *)hd, n16);
                     ce = hipGetLastError();
                 } else {
                     (void)hipGetLastError();
-                    ce = hipMemcpyAsync(S.h_text.p, SL.d_text.p, used, hipMemcpyDeviceToHost, sarr[cur.slot]);
+                    ce = hipMemcpyAsync(S.text_p, SL.d_text.p, used, hipMemcpyDeviceToHost, sarr[cur.slot]);
                 }
             }
             if (ce == hipSuccess && overflow) {

@@ -32,6 +32,11 @@ struct poa_item {
     std::vector<uint32_t> rows;    // AbpoaAlignmentResult.abpoa_nodes: 1-based base-row id per graph-consuming column
     std::vector<uint32_t> gnodes;  // AbpoaAlignmentResult.graph_nodes
     std::string cigar, cs;
+    // (device text, poa_feed::keep_text) views into the launch's text as it came back -- valid until the context's next POA call;
+    // when cs_p is set, cs / cigar / gnodes above are empty
+    const char *cs_p = nullptr, *cigar_p = nullptr;
+    const uint32_t *gnodes_p = nullptr;
+    uint32_t cs_n = 0, cigar_n = 0, gnodes_n = 0;
 };
 
 struct poa_timing {
@@ -52,6 +57,9 @@ struct poa_feed {
     std::function<void(const uint32_t *ids, uint64_t cnt)> prepare;
     const double *proxy = nullptr;
     const sg_store *dev = nullptr;
+    bool keep_text = false;  // device text (K4c) stays where it came back, one pinned buffer per launch, and the items point into it
+                             // (poa_item::cs_p ...): the caller copies each string once, into its result.  The buffers belong to the
+                             // context and are recycled by its next POA call
     std::function<int()> dev_rest;  // prepares the store's second part (problems >= dev->split); called once, when they are first needed
     // optional: the launch order itself (n problem indices; poa_run then does not sort by proxy) and a class per problem
     // (1 = very long: such problems are launched apart, with the largest workgroup and window)
