@@ -186,10 +186,11 @@ struct vga_hbuf {
         mapped = 0;
         const size_t want = n + n / 8 + 64;
         const size_t bytes = (want * sizeof(T) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-        if (bytes >= ((size_t)8 << 20)) {
+        static const int pin_mode = getenv("VGA_PINNED") ? atoi(getenv("VGA_PINNED")) : 0;  // diagnostics: 1 hipHostMalloc only, 2 register without huge pages
+        if (bytes >= ((size_t)8 << 20) && pin_mode != 1) {
             void *q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
             if (q != MAP_FAILED) {
-                (void)madvise(q, bytes, MADV_HUGEPAGE);
+                if (pin_mode != 2) (void)madvise(q, bytes, MADV_HUGEPAGE);
                 if (hipHostRegister(q, bytes, hipHostRegisterDefault) == hipSuccess) {
                     p = (T *)q;
                     cap = want;

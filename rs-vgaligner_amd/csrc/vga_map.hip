@@ -278,9 +278,21 @@ __device__ __forceinline__ void vga_chain_dp(uint32_t lane, uint64_t a0, uint32_
 {
     const double kd = (double)k;
     const double NEGMAX = -1.7976931348623157e308;  // -f64::MAX
+    // gaps are differences of 32-bit coordinates: compared with min(max_gap, 2^32 - 1) in 32 bits
+    const uint32_t max_gap32 = max_gap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_gap;
+    const int k1000 = (int)(k * 1000u);  // (IKEY) f(i) = k is beaten exactly by the integers above 1000 k
+    int ckey = 0;                        // (IKEY) the running maximum as an integer: curr_max starts at 0.0 (src/chain.rs:400)
     double f_l = 0.0;
     uint32_t qb_l = 0, tb_l = 0, te_l = 0;
     int j_l = -1, pj_l = -1;
+    // x / 1000.0 without the division sequence (v_rcp_f64 and ten more): q = x c, r = fma(-q, 1000, x), q + r c with c = 1 / 1000 is
+    // the correctly rounded quotient for EVERY 32-bit integer x (tests/test_chain_arith_cpu.py checks all of them on the host)
+    auto div1000 = [](int x) -> double {
+        const double xd = (double)x, c = 1.0 / 1000.0;
+        const double q = xd * c;
+        const double r = __builtin_fma(-q, 1000.0, xd);
+        return __builtin_fma(r, c, q) + 0.0;
+    };
 
     for (uint32_t base = 0; base < A; base += 64) {
         const uint32_t nb = A - base < 64 ? A - base : 64;
@@ -292,55 +304,44 @@ __device__ __forceinline__ void vga_chain_dp(uint32_t lane, uint64_t a0, uint32_
             const uint32_t tbi = (uint32_t)__builtin_amdgcn_readlane((int)ct, (int)ii);
             const uint32_t tei = (uint32_t)__builtin_amdgcn_readlane((int)ce, (int)ii);
             double p = NEGMAX;
-            int key = INT32_MIN;  // (IKEY) round(1000 s) of this lane's candidate; no real score reaches INT32_MIN
             int j = -1;
+            bool take = false;  // (IKEY) the step's best candidate beats f(i) = k
+            int kbest = INT32_MIN;
             if (i > 0) {
                 const int min_j = (bandwidth > i) ? 0 : (int)(i - bandwidth);  // src/chain.rs:404-407
-                bool ok = false;
-                if (j_l >= min_j) {
-                    // score_anchor(a = j_l, b = i), src/chain.rs:274-368.  Bit 31 of a target coordinate is its orientation
-                    // (always 0 with only_forward): the four ends must agree (chain.rs:280-283), then positions compare
-                    const uint32_t ob = tei >> 31;
-                    const bool same = (tb_l >> 31) == ob && (te_l >> 31) == ob && (tbi >> 31) == ob;
-                    if (same && !(qb_l >= qbi || te_l >= tei)) {
-                        const uint64_t ql = (uint64_t)(qbi - qb_l);
-                        const uint64_t tbd = tbi > tb_l ? (uint64_t)(tbi - tb_l) : (uint64_t)(tb_l - tbi);
-                        const uint64_t ted = (uint64_t)(tei - te_l);
-                        const uint64_t tl = tbd < ted ? tbd : ted;
-                        const uint64_t g = ql > tl ? ql - tl : tl - ql;
-                        if (g <= max_gap) {
-                            const double gc = GAP_LDS ? s_gap[g] : gap_cost[g];
-                            uint64_t ml = ql < tl ? ql : tl;
-                            if ((uint64_t)k < ml) ml = k;
-                            double s = f_l + (double)ml;
-                            s = s - gc;
-                            s = s * 1000.0;
-                            s = round(s);
-                            if constexpr (IKEY) key = (int)s;
-                            else {
-                                s = s / 1000.0;
-                                s = s + 0.0;
-                                p = s;
-                            }
-                            ok = true;
-                        }
+                // score_anchor(a = j_l, b = i), src/chain.rs:274-368, as ONE predicate over cheap integer work (the nested form
+                // cost four exec-mask round trips per step).  Bit 31 of a target coordinate is its orientation (always 0 with
+                // only_forward): the four ends must agree (chain.rs:280-283), then positions compare
+                const uint32_t ob = tei >> 31;
+                const uint32_t ql = qbi - qb_l;
+                const uint32_t tbd = tbi > tb_l ? tbi - tb_l : tb_l - tbi;
+                const uint32_t ted = tei - te_l;
+                const uint32_t tl = tbd < ted ? tbd : ted;
+                const uint32_t g = ql > tl ? ql - tl : tl - ql;
+                const bool ok = j_l >= min_j && (tb_l >> 31) == ob && (te_l >> 31) == ob && (tbi >> 31) == ob && qb_l < qbi && te_l < tei &&
+                                g <= max_gap32;
+                int key = INT32_MIN;  // (IKEY) round(1000 s) of this lane's candidate; no real score reaches INT32_MIN
+                if (ok) {
+                    const double gc = GAP_LDS ? s_gap[g] : gap_cost[g];
+                    uint32_t ml = ql < tl ? ql : tl;
+                    if (k < ml) ml = k;
+                    double s = f_l + (double)ml;
+                    s = s - gc;
+                    s = s * 1000.0;
+                    s = round(s);
+                    if constexpr (IKEY) key = (int)s;
+                    else {
+                        s = s / 1000.0;
+                        s = s + 0.0;
+                        p = s;
                     }
                 }
                 // the maximum, then the largest j among the lanes that hold it (src/chain.rs:417,430: the scan runs from
                 // i-1 downwards with a strict '>')
                 uint64_t mask;
                 if constexpr (IKEY) {
-                    const int kmax = __builtin_amdgcn_readlane(vga_wave_max_i32_to_lane63(key), 63);
-                    mask = kmax != INT32_MIN ? __ballot(key == kmax) : 0ull;
-                    // kmax / 1000.0 without the division sequence (v_rcp_f64 and ten more): q = x c, r = fma(-q, 1000, x), q + r c
-                    // with c = 1 / 1000 is the correctly rounded quotient for EVERY 32-bit integer x -- checked exhaustively on the
-                    // host (tests/test_chain_arith_cpu.py runs the check)
-                    {
-                        const double x = (double)kmax, c = 1.0 / 1000.0;
-                        const double q = x * c;
-                        const double r = __builtin_fma(-q, 1000.0, x);
-                        p = __builtin_fma(r, c, q) + 0.0;
-                    }
+                    kbest = __builtin_amdgcn_readlane(vga_wave_max_i32_to_lane63(key), 63);
+                    mask = kbest != INT32_MIN ? __ballot(key == kbest) : 0ull;
                 } else {
                     const double red = vga_wave_max_f64_to_lane63(p);
                     const double pmax = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(red), 63),
@@ -353,12 +354,22 @@ __device__ __forceinline__ void vga_chain_dp(uint32_t lane, uint64_t a0, uint32_
                     const uint64_t rot = sft ? ((mask << sft) | (mask >> (64u - sft))) : mask;
                     const int d = __builtin_clzll(rot);  // 0 for the lane of anchor i-1
                     j = (int)i - 1 - d;
+                    if constexpr (IKEY) {
+                        // p > k and p > curr_max are decided on the integers (x -> x / 1000 is strictly increasing, 1000 k / 1000 = k):
+                        // scalar compares instead of f64 compares and selects in every lane
+                        take = kbest > k1000;
+                        ckey = kbest > ckey ? kbest : ckey;
+                    }
                 } else p = NEGMAX;
             }
             double fi = kd;  // src/chain.rs:163: initial f(i) = k
             int pj = -1;
-            if (p > fi) { fi = p; pj = j; }
-            if (p > curr_max) curr_max = p;
+            if constexpr (IKEY) {
+                if (take) { fi = div1000(kbest); pj = j; }
+            } else {
+                if (p > fi) { fi = p; pj = j; }
+                if (p > curr_max) curr_max = p;
+            }
             if (lane == ii) { f_l = fi; qb_l = cq; tb_l = ct; te_l = ce; j_l = (int)i; pj_l = pj; }
         }
         // lane l now holds f and the predecessor of anchor base + l
@@ -368,6 +379,7 @@ __device__ __forceinline__ void vga_chain_dp(uint32_t lane, uint64_t a0, uint32_
             pred_id_out[a0 + base + lane] = pj_l >= 0 ? (int32_t)s_id[a0 + pj_l] : -1;
         }
     }
+    if constexpr (IKEY) curr_max = ckey > 0 ? div1000(ckey) : 0.0;
 }
 
 template <bool GAP_LDS>
