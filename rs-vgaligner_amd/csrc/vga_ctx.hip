@@ -124,8 +124,9 @@ extern "C" int vga_ctx_create(int device, vga_ctx **out)
         const char *tm = getenv("VGA_TUNE_MALLOC");
         if (tm && atoi(tm) != 0)
             std::call_once(tuned, []() {
-                mallopt(M_MMAP_THRESHOLD, 1 << 30);
-                mallopt(M_TRIM_THRESHOLD, INT32_MAX);
+                mallopt(M_MMAP_THRESHOLD, INT32_MAX);
+                mallopt(M_TRIM_THRESHOLD, -1);  // (never: with a finite threshold a step that frees more than it -- 25 000 config-5 reads:
+                                                // 3 x 0.6 GB of anchor arrays -- gives the pages back and faults them in again next step)
                 mallopt(M_TOP_PAD, 256 << 20);
             });
     }

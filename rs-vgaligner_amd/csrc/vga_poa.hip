@@ -618,6 +618,15 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     if (feed.klass)
         for (uint64_t p = 0; p < n && !any_long; p++) any_long = feed.klass[p] != 0;
     int n_slots = arena_wanted ? (any_long || !feed.klass ? 3 : 2) : 2;
+    // ... and when the call's problems are narrow-band (k_poa_dp_t6's launches: 2 048 single-wave workgroups each, two of them are
+    // exactly the GPU's 4 096 wave slots): while the first of two launches drains, its freed slots stay empty until it has ended
+    // and the next one is staged -- with a third launch in flight they are taken at once (config 5: 58 200 -> 66 400 reads/s,
+    // same box; four: 62 700; config 3, wide bands: 9 410 with two, 9 330 with three)
+    {
+        double wsum = 0;
+        for (uint64_t i = 0; i < n_probe; i++) wsum += estw[order[i]];
+        if (arena_wanted && wsum / (double)n_probe <= 800.0) n_slots = 3;
+    }
     if (const char *e = getenv("VGA_POA_SLOTS")) n_slots = std::max(1, std::min(POA_SLOTS, atoi(e)));
     hipStream_t sarr[POA_SLOTS];
     sarr[0] = st;
@@ -834,7 +843,9 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         // (device store: a launch gathers from one part of it)
         if (feed.dev && feed.dev->split > i0 && feed.dev->split < cap) cap = feed.dev->split;
         while (i1 < cap) {
-            if (!ready[order[i1]]) ensure(i1, std::min<uint64_t>(cap, i1 + 256));
+            // (device store: a problem's preparation is a copy of its sizes -- a whole launch's worth in one fan-out; 256 at a time
+            // cost eight thread fan-outs per launch, 6-7 ms before each of a call's first two launches with the GPU idle)
+            if (!ready[order[i1]]) ensure(i1, std::min<uint64_t>(cap, i1 + (feed.dev ? 4096 : 256)));
             if (malformed || dev_failed) break;
             const double e = est[order[i1]] * W.pool_scale + 3.0 * (double)POA_CHUNK;
             if (!arena && i1 > i0 && used_est + e > budget) break;

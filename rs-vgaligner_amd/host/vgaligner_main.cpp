@@ -169,7 +169,7 @@ int main(int argc, char **argv)
     if (!getenv("VGA_NO_TUNE_MALLOC")) {
         mallopt(M_ARENA_MAX, 1);
         mallopt(M_MMAP_THRESHOLD, INT32_MAX);
-        mallopt(M_TRIM_THRESHOLD, INT32_MAX);
+        mallopt(M_TRIM_THRESHOLD, -1);  // (never)
         mallopt(M_TOP_PAD, 256 << 20);
     }
     try {
