@@ -297,6 +297,9 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     std::vector<sg_desc> descs(on_device ? n : 0);
     std::vector<uint64_t> q_src(on_device ? n : 0);
     std::atomic<int> has_reverse{0};
+    // (rows: 24 000 and more -- config 3's longest problems have 21 000-22 000 rows and stay in the ordinary launches; config 4's
+    // bubble-rich problems of 24 000-38 000 rows, whose band is as wide as the query on every row, do not)
+    const uint32_t giant_rows = getenv("VGA_GIANT_ROWS") ? (uint32_t)atol(getenv("VGA_GIANT_ROWS")) : 24000u;
     vga_parallel_for(n, [&](uint64_t p) {
         const uint64_t r = prob_read[p], c = prob_chain[p];
         const uint64_t a0 = m->anchor_off[r];
@@ -322,6 +325,12 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
         const double rows = (double)(hi > lo ? hi - lo : 0) + 1.6 * uncovered;
         west[p] = (float)(650.0 + 0.3 * std::max(0.0, 0.85 * rows - (double)ql));
         proxy[p] = rows * (double)west[p];
+        // a chain whose span alone makes it a long problem goes to the front of the order whatever its width term: it must be in the
+        // first part of the store, where its actual rows are known before the launch of the long problems starts -- config 4: 21
+        // problems of 24 000-37 000 rows sat behind position 2 048, were launched as a second group of long problems 80 ms into
+        // the call and, 1 024-thread workgroups that need a CU's 16 wave slots at once, only got their CUs when the bulk launch
+        // beside them had nothing left to dispatch: they ended last, 512 ms after their launch
+        if (rows >= 0.85 * (double)giant_rows) proxy[p] += 1e13;
         feed.views[p] = {nullptr, nullptr, 0, nullptr, nullptr, 0, b->reads.data() + b->read_off[r], ql};
         if (on_device) {
             const uint64_t fa = a0 + m->chain_anchor_idx[c0], la = a0 + m->chain_anchor_idx[c1 - 1];
@@ -361,9 +370,6 @@ static int vga_align_batch_impl(vga_batch *b, const vga_map_result *m, uint32_t 
     // config 4, as long as the 107 000-row problem takes in the launch of the long ones.  The product rows x expected width
     // (poa_run's estimate: from the longest source-sink path) decides.
     const double giant_cells = getenv("VGA_GIANT_CELLS") ? atof(getenv("VGA_GIANT_CELLS")) : 1.5e8;
-    // (rows: 24 000 and more -- config 3's longest problems have 21 000-22 000 rows and stay in the ordinary launches; config 4's
-    // bubble-rich problems of 24 000-38 000 rows, whose band is as wide as the query on every row, do not)
-    const uint32_t giant_rows = getenv("VGA_GIANT_ROWS") ? (uint32_t)atol(getenv("VGA_GIANT_ROWS")) : 24000u;
     std::function<uint8_t(uint64_t)> is_giant = [&](uint64_t i) -> uint8_t {  // (function scope: feed.dev_rest calls it from inside poa_run)
         const sg_sum &sm = store.sum[i];
         if (sm.N >= giant_rows) return 1;
