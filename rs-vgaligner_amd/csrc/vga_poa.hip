@@ -1163,7 +1163,8 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         if (text_on_device) {
             // K4c: the strings and the node path are written where the operations are (vga_poa_text.hpp); what crosses PCIe now is a
             // record per problem and the counter of the arena -- the text itself follows when the host knows how much there is
-            const uint64_t arena = std::min<uint64_t>(2ull * tot_ops + 64ull * nb + 4096ull, 0xF0000000ull);
+            uint64_t arena = std::min<uint64_t>(2ull * tot_ops + 64ull * nb + 4096ull, 0xF0000000ull);
+            if (const char *e = getenv("VGA_POA_TEXT_ARENA")) arena = std::min<uint64_t>(arena, strtoull(e, nullptr, 10));  // (testing: the overflow path)
             chk(S.d_text.reserve(arena + 16)); chk(S.d_touts.reserve(nb)); chk(S.d_tcur.reserve(1));
             chk(O.h_touts.reserve(nb)); chk(O.h_tcur.reserve(1));
             if (launch_err == hipSuccess) {

@@ -157,6 +157,20 @@ def test_map_config3_sample_and_edge_reads(oracle, ctx, drb1):
     compare_map(oracle, ix, ctx.batch(seqs).map(), seqs)
 
 
+def test_chaining_argmax_in_f64_matches_the_integer_one(oracle, ctx, drb1, monkeypatch):
+    """K3 takes a step's argmax on round(1000 score) as 32-bit integers when a read's scores fit (every read of the workloads);
+    reads with more than ~195 000 anchors keep the f64 reduction.  VGA_CHAIN_F64=1 sends every read through that path: the same
+    f(i) bits, predecessors and chains (src/chain.rs:398-450)."""
+    _, ix = drb1
+    upload_oracle_index(ctx, ix)
+    reads = pkg().readsim.config3_reads(DRB1, 8)
+    seqs = [r.seq for r in reads] + [r.seq for r in pkg().readsim.config2_reads(DRB1, 100)] + ["", "ACGT"]
+    monkeypatch.setenv("VGA_CHAIN_F64", "1")
+    compare_map(oracle, ix, ctx.batch(seqs).map(), seqs)
+    monkeypatch.delenv("VGA_CHAIN_F64")
+    compare_map(oracle, ix, ctx.batch(seqs).map(), seqs)
+
+
 def test_map_parameters(oracle, ctx, drb1):
     """non-default bandwidth / max_gap / min_anchors follow the oracle too"""
     _, ix = drb1
@@ -334,6 +348,18 @@ def test_align_config3_sample(oracle, ctx, drb1):
     upload_oracle_index(ctx, ix)
     _check_align(oracle, ctx, ix, pkg().readsim.simulate_reads(DRB1, 10, 2500, 0.03, 0.03, 0.04, seed=11))
     _check_align(oracle, ctx, ix, pkg().readsim.config3_reads(DRB1, 3))
+
+
+def test_text_arena_too_small_for_some_problems_falls_back_to_their_operations(oracle, ctx, drb1, monkeypatch):
+    """k_poa_text claims a problem's place in the launch's text arena with one atomic add; a problem that finds the arena full is
+    flagged and its operations come back instead, encoded on the host -- in one call beside problems whose strings came from the
+    device (VGA_POA_TEXT_ARENA pins a small arena).  Records equal the oracle's either way (src/align.rs:1096-1168)."""
+    gfa, ix = drb1
+    upload_oracle_index(ctx, ix)
+    reads = pkg().readsim.config3_reads(DRB1, 6)
+    monkeypatch.setenv("VGA_POA_TEXT_ARENA", "30000")  # (a 10 kbp read's cs + CIGAR + path take ~18 KB: one or two fit)
+    al = _check_align(oracle, ctx, ix, reads)
+    assert sum(al.aligned) == 6
 
 
 def test_value_row_ring_keeps_rows_of_unequal_width(oracle, ctx, drb1):
