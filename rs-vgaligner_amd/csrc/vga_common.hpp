@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -69,6 +70,10 @@ struct vga_ctx {
     // entry point that starts on this context while it is idle, and with the context
     std::mutex deferred_mu;
     std::vector<vga_deferred> deferred;
+    // buffers of this context that are being allocated right now (vga_dbuf / vga_hbuf::reserve): the thread that grows the POA pool
+    // in the background holds back while this is not zero -- the runtime serialises allocations, and every small hipMalloc of a call
+    // otherwise waits for one of the grower's 4 GiB segments (0.1-0.25 s each while the driver clears them)
+    std::atomic<int> alloc_urgent{0};
     vga_dev_index index;
     // per-call kernel timing (events recorded on `stream`)
     std::vector<vga_timer_entry> timers;
@@ -125,6 +130,14 @@ int vga_set_error(vga_ctx *ctx, int code, const char *fmt, ...);
 // threads they start), which that context's next entry point releases while it is idle (vga_release_deferred) -- never another
 // context's, whose launches may be in flight -- and vga_ctx_destroy.  Outside any context the memory is released at once.
 void vga_defer_release(void *device_ptr, void *pinned_ptr, void *registered_ptr, size_t registered_bytes);
+// the calling thread's context (if any) has an allocation in progress: vga_ctx::alloc_urgent
+struct vga_alloc_urgent {
+    vga_alloc_urgent();
+    ~vga_alloc_urgent();
+    vga_alloc_urgent(const vga_alloc_urgent &) = delete;
+    vga_alloc_urgent &operator=(const vga_alloc_urgent &) = delete;
+    void *ctx_;
+};
 void vga_release_deferred(vga_ctx *ctx);
 vga_ctx *vga_current_ctx();
 struct vga_ctx_scope {  // the context the calling thread works for, for the lifetime of the object
@@ -143,6 +156,7 @@ struct vga_dbuf {
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
+        vga_alloc_urgent urgent;
         if (p) vga_defer_release(p, nullptr, nullptr, 0);
         p = nullptr;
         cap = 0;
@@ -180,6 +194,7 @@ struct vga_hbuf {
     hipError_t reserve(size_t n)
     {
         if (n <= cap) return hipSuccess;
+        vga_alloc_urgent urgent;
         if (p) vga_defer_release(nullptr, mapped ? nullptr : p, mapped ? p : nullptr, mapped);
         p = nullptr;
         cap = 0;

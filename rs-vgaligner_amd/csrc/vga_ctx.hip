@@ -50,6 +50,8 @@ void release_one(const vga_deferred &d)
 }  // namespace
 
 vga_ctx *vga_current_ctx() { return t_current_ctx; }
+vga_alloc_urgent::vga_alloc_urgent() : ctx_(t_current_ctx) { if (ctx_) ((vga_ctx *)ctx_)->alloc_urgent.fetch_add(1); }
+vga_alloc_urgent::~vga_alloc_urgent() { if (ctx_) ((vga_ctx *)ctx_)->alloc_urgent.fetch_sub(1); }
 vga_ctx_scope::vga_ctx_scope(vga_ctx *ctx) : prev(t_current_ctx) { t_current_ctx = ctx; }
 vga_ctx_scope::~vga_ctx_scope() { t_current_ctx = prev; }
 

@@ -246,6 +246,7 @@ struct poa_ws {
     bool growing = false, grow_failed = false;
     std::thread grower;
     int device = 0;
+    vga_ctx *owner = nullptr;  // (the grower holds back while owner->alloc_urgent: vga_common.hpp)
     uint64_t seg_bytes = 1ull << POA_SEG_LOG2;
     // chunk pool (device side)
     vga_dbuf<unsigned long long> d_head;  // the free-list heads (POA_LISTS of them, a cache line apart), then the statistics
@@ -268,14 +269,43 @@ struct poa_ws {
         const hipError_t e = hipMemcpy(d_head.p, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice);
         return e != hipSuccess ? e : hipStreamSynchronize(nullptr);  // (the copy is on the device before anything is launched: see d_slot_flag)
     }
+    // The small tables of the chunk pool (free-list heads, per-chunk links, state-region flags, the segment table and its pinned
+    // staging, the kernels' shortage flag, the stream new segments are listed on).  Allocated BEFORE the grower is started: the
+    // runtime serialises allocations, and a 16 KB hipMalloc or hipHostMalloc that queues behind the grower's 4 GiB segments
+    // (0.1 s each while the driver clears them) held the first launch of a process back by 1.8-5.3 s
+    bool tables_ready = false;
+    hipError_t ensure_tables(uint32_t n_cu)
+    {
+        if (tables_ready) return hipSuccess;
+        const uint32_t max_chunks = (uint32_t)(POA_MAX_SEGS * (1ull << (POA_SEG_LOG2 - 20)));
+        hipError_t e;
+        if ((e = d_head.reserve(POA_LISTS * POA_LIST_STRIDE + 16)) != hipSuccess) return e;
+        if ((e = d_next_chunk.reserve(max_chunks)) != hipSuccess) return e;
+        if ((e = d_slot_flag.reserve(16ull * (uint64_t)n_cu + 64)) != hipSuccess) return e;
+        if ((e = h_seg_base.reserve(POA_MAX_SEGS)) != hipSuccess) return e;
+        if ((e = h_short.reserve(16)) != hipSuccess) return e;
+        h_short.p[0] = 0;
+        if ((e = d_seg_base.reserve(POA_MAX_SEGS)) != hipSuccess) return e;
+        if (!add_stream) {
+            // (highest priority: when the pool does run short with the GPU full, the kernel that lists a new segment must be the
+            // first to get the slot a workgroup frees)
+            int pr_lo = 0, pr_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+            if ((e = hipStreamCreateWithPriority(&add_stream, hipStreamNonBlocking, pr_hi)) != hipSuccess) return e;
+            if ((e = reset_lists()) != hipSuccess) return e;
+        }
+        tables_ready = true;
+        return hipSuccess;
+    }
     // vga_align_prepare: the state regions and the first segments, allocated on a thread of its own before the first
     // vga_align_batch call needs them (on memory another process used the driver clears what it hands out: 13 GB = 0.2 s)
     std::thread preparer;
-    void prepare_async(uint64_t state_want, uint64_t pool_want)
+    void prepare_async(uint64_t state_want, uint64_t pool_want, uint32_t n_cu)
     {
         join_preparer();
-        preparer = std::thread([this, state_want, pool_want]() {
+        preparer = std::thread([this, state_want, pool_want, n_cu]() {
             (void)hipSetDevice(device);
+            if (ensure_tables(n_cu) != hipSuccess) (void)hipGetLastError();  // (poa_run asks again, and reports)
             if (state_bytes < state_want) {
                 uint8_t *q = nullptr;
                 if (hipMalloc((void **)&q, state_want) == hipSuccess) {
@@ -323,6 +353,17 @@ struct poa_ws {
                     std::lock_guard<std::mutex> lk2(mu);
                     if (pool_size >= grow_target || segs.size() >= POA_MAX_SEGS) { growing = false; cv.notify_all(); return; }
                     want = std::min<uint64_t>(seg_bytes, (grow_target - pool_size + POA_CHUNK - 1) & ~(POA_CHUNK - 1));
+                }
+                // allocations of the context's calls go first: none in progress, and none for the last 3 ms (a call reserves its
+                // buffers one after the other)
+                if (owner) {
+                    auto quiet_since = std::chrono::steady_clock::now();
+                    for (;;) {
+                        if (owner->alloc_urgent.load() > 0) quiet_since = std::chrono::steady_clock::now();
+                        else if (std::chrono::steady_clock::now() - quiet_since >= std::chrono::milliseconds(3)) break;
+                        { std::lock_guard<std::mutex> lk2(mu); if (grow_target == 0) break; }  // (stop_grower)
+                        std::this_thread::sleep_for(std::chrono::microseconds(300));
+                    }
                 }
                 uint8_t *q = nullptr;
                 const hipError_t e = hipMalloc((void **)&q, want);
@@ -387,6 +428,7 @@ extern "C" int vga_align_prepare(vga_ctx *ctx, uint64_t n_reads, uint32_t max_re
     }
     poa_ws &W = *(poa_ws *)ctx->poa_ws;
     W.device = ctx->device;
+    W.owner = ctx;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return VGA_OK;
     uint64_t avail = free_b > (16ull << 30) ? (uint64_t)((double)free_b * 0.85) : free_b / 4;
@@ -411,7 +453,7 @@ extern "C" int vga_align_prepare(vga_ctx *ctx, uint64_t n_reads, uint32_t max_re
     const uint64_t resident = std::min<uint64_t>(n_reads, std::max<uint64_t>(32, (uint64_t)(6.0 * (double)ctx->n_cu * share)));
     uint64_t pool_want = (uint64_t)std::min<double>((double)resident * per_problem * 0.35, (double)avail / 4.0) & ~(POA_CHUNK - 1);
     if (pool_want < 16 * POA_CHUNK) pool_want = 0;
-    W.prepare_async(ns * state_size, pool_want);
+    W.prepare_async(ns * state_size, pool_want, (uint32_t)ctx->n_cu);
     return VGA_OK;
 }
 
@@ -564,6 +606,7 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
     for (uint64_t i = 0; i < n_probe; i++) { probe_sum += est[order[i]]; probe_big = std::max(probe_big, est[order[i]]); }
     const double probe_mean = probe_sum / (double)n_probe;
     W.device = ctx->device;
+    W.owner = ctx;
     // what this context may take of the GPU: everything else it allocates (staging of three sub-batches, the subgraph store,
     // the map workspace) keeps 15 % of what is free, at least 16 GB -- two processes sharing a GPU otherwise starve each other
     uint64_t avail_pool = 0;
@@ -650,7 +693,22 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
         const uint64_t resident = std::min<uint64_t>(n, 6ull * (uint64_t)ctx->n_cu);
         double fill = 0.7;
         if (const char *e = getenv("VGA_POOL_FILL")) fill = atof(e);
-        uint64_t want = (uint64_t)((double)resident * probe_mean * W.pool_scale * fill) + 64 * POA_CHUNK;
+        // what is resident at a time: every long problem of the call (a launch of their own, one CU each: poa_feed::klass) and
+        // `resident` workgroups of the others.  The probe is the head of the launch order, where the long problems stand: their
+        // footprints are summed, not taken for the mean of the rest (config 4, 12 000 reads: 217 GB asked for where 75 GB do)
+        double long_sum = 0, bulk_sum = 0;
+        uint64_t long_cnt = 0, bulk_cnt = 0, long_all = 0;
+        if (feed.klass) {
+            for (uint64_t p = 0; p < n; p++) long_all += feed.klass[p] != 0;
+            for (uint64_t i = 0; i < n_probe; i++) {
+                if (feed.klass[order[i]]) { long_sum += est[order[i]]; long_cnt++; }
+                else { bulk_sum += est[order[i]]; bulk_cnt++; }
+            }
+            if (long_cnt && long_all > long_cnt) long_sum *= (double)long_all / (double)long_cnt;
+        } else { bulk_sum = probe_sum; bulk_cnt = n_probe; }
+        const double bulk_mean = bulk_cnt ? bulk_sum / (double)bulk_cnt : probe_mean;
+        const uint64_t bulk_resident = std::min<uint64_t>(n - std::min<uint64_t>(n, long_all), resident);
+        uint64_t want = (uint64_t)((long_sum + (double)bulk_resident * bulk_mean) * W.pool_scale * fill) + 64 * POA_CHUNK;
         want = std::max<uint64_t>(want, (uint64_t)(probe_big * W.pool_scale * 1.5));
         want = std::min<uint64_t>(want, avail_pool > ns * state_size ? avail_pool - ns * state_size : avail_pool / 2);
         want = (want + POA_CHUNK - 1) & ~(POA_CHUNK - 1);
@@ -673,27 +731,26 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 if (const char *e = getenv("VGA_POOL_SEG")) W.seg_bytes = std::max<uint64_t>(16 * POA_CHUNK, strtoull(e, nullptr, 10) & ~(POA_CHUNK - 1));
                 W.seg_bytes = std::min<uint64_t>(W.seg_bytes, 1ull << POA_SEG_LOG2);  // (chunks are numbered segment << 12 | chunk in segment)
             }
+            tr.mark("pool: state regions");
+            POA_CHECK(W.ensure_tables((uint32_t)ctx->n_cu));
+            tr.mark("pool: tables");
             W.request(want);
-            const uint64_t got = W.wait_for(std::min<uint64_t>(want, W.seg_bytes));
+            // The launches start when the pool holds what their resident workgroups need: on memory that was used before, the driver
+            // clears a segment as it hands it out (0.1 s per 4 GiB), and launches that fill the GPU with workgroups waiting for chunks
+            // leave the kernel that lists new segments no slot to run in (a 12 000-read call of config 4 that started with a sixth
+            // of its pool took 19 s).  On fresh memory this waits a few milliseconds.
+            const uint64_t got = W.wait_for(want);
+            tr.mark("pool: segments");
             if (got >= 16 * POA_CHUNK) {
                 const uint32_t max_chunks = (uint32_t)(POA_MAX_SEGS * (1ull << (POA_SEG_LOG2 - 20)));
-                POA_CHECK(W.d_head.reserve(POA_LISTS * POA_LIST_STRIDE + 16));
-                POA_CHECK(W.d_next_chunk.reserve(max_chunks));
-                POA_CHECK(W.d_slot_flag.reserve(16ull * (uint64_t)ctx->n_cu + 64));
-                POA_CHECK(W.h_seg_base.reserve(POA_MAX_SEGS));
-                POA_CHECK(W.h_short.reserve(16));
                 W.h_short.p[0] = 0;
-                POA_CHECK(W.d_seg_base.reserve(POA_MAX_SEGS));
-                if (!W.add_stream) {
-                    POA_CHECK(hipStreamCreateWithFlags(&W.add_stream, hipStreamNonBlocking));
-                    POA_CHECK(W.reset_lists());
-                }
                 // (on the context's stream, and waited for: hipMemset runs on the null stream and may return before the device has
                 // done it -- no stream of this library waits for the null stream, and on a GPU that other contexts keep full the
                 // flags were cleared AFTER the first workgroups of slots 1 and 2 had taken their state regions: a second workgroup
                 // took the same region, and both problems came back with wrong alignments)
                 POA_CHECK(hipMemsetAsync(W.d_slot_flag.p, 0, ns * sizeof(uint32_t), st));
                 POA_CHECK(hipStreamSynchronize(st));
+                tr.mark("pool: flags cleared");
                 n_arenas = (uint32_t)ns;
                 CP.head = W.d_head.p; CP.next = W.d_next_chunk.p; CP.seg_base = W.d_seg_base.p;
                 CP.cps_log2 = POA_SEG_LOG2 - 20; CP.n_slots = n_arenas; CP.state_base = W.state; CP.state_size = state_size;
