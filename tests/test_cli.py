@@ -172,8 +172,8 @@ def test_cli_eight_contexts_on_one_gpu_rehearse_an_eight_gpu_node(tmp_path, conf
     0,0,0,0,0,0,0,0 --chunk-reads 1500` -- eight contexts and eight host threads, each context told its eighth of the GPU's memory
     (vga_ctx_set_pool_fraction) and of the host's threads (vga_ctx_set_host_threads), chunk pools that start small and grow under
     their keeper threads -- on 12 000 full-length reads of the merged HLA graph, against one context: byte-identical GAF files in
-    read order (src/map.rs:56-111,162-167).  Wall times of both runs are printed (pytest -s; round 4 on GPU boxes: 3.6-7.4 s for one
-    context, 11.5-16.2 s for eight, box to box -- eight contexts time-slice one GPU, each allocates its own state regions and pool
+    read order (src/map.rs:56-111,162-167).  Wall times of both runs are printed (pytest -s; round 4 on GPU boxes: 1.5-2.2 s for one
+    context, 7.3-10.5 s for eight, box to box -- eight contexts time-slice one GPU, each allocates its own state regions and pool
     segments, which the driver serialises and clears, each uploads the index and runs its own longest problems beside the others'
     bulk launches) and must stay within a factor of 6: what the test guards against is the small-share cliff of round 3 (a
     context with a fifth of the pool ran 40x slower before the keeper thread), not the cost of rehearsing eight GPUs on one."""
