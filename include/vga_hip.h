@@ -183,10 +183,11 @@ typedef struct {
 } vga_poa_params;
 /* remain[row] = graph bases after the row on one path to the sink.  abPOA's source is not in the reference tree, so which
  * path it takes is unverified; both readings are implemented and parity-tested (oracle/og_poa.c):
- *   LONGEST_PATH   the longest path to the sink (rounds 1-2 of this library);
+ *   LONGEST_PATH   the longest path to the sink (the default of rounds 1-3 of this library);
  *   FIRST_OUT_EDGE the path that follows the heaviest out-edge, the first on a tie -- abPOA's abpoa_BFS_set_node_remain
  *                  as remembered; with the unit weights of a graph built from node strings + an edge list that is the
- *                  first out-edge in edge-list order. */
+ *                  first out-edge in edge-list order.  vga_poa_default_params sets this one since round 4: it is the
+ *                  reading most likely to reproduce the reference's scores and CIGARs. */
 #define VGA_REMAIN_LONGEST_PATH 0
 #define VGA_REMAIN_FIRST_OUT_EDGE 1
 void vga_poa_default_params(vga_poa_params *p);

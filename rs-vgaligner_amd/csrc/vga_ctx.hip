@@ -506,6 +506,6 @@ extern "C" void vga_poa_default_params(vga_poa_params *p)
     p->gap_open2 = 24;
     p->gap_ext2 = 1;
     p->wb = 10;
-    p->remain_rule = VGA_REMAIN_LONGEST_PATH;
+    p->remain_rule = VGA_REMAIN_FIRST_OUT_EDGE;  // (since round 4: include/vga_hip.h)
     p->wf = 0.01;
 }
