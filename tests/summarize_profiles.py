@@ -72,7 +72,7 @@ if os.path.exists(ip):
         lines.append(",".join([r["Dispatch_Id"], r["Kernel_Name"][:32].replace(",", ";"), r["Counter_Name"], r["Counter_Value"]]))
     for k, v in sorted(tot.items()): lines.append(f"# sum {k} = {v}")
     open(os.path.join(dst, f"{rnd}_{tag}_pmc_insts.txt"), "w").write("\n".join(lines) + "\n")
-    cells = last("bench_pmc_INSTS.json")["poa_cells_per_step"] if "poa_cells_per_step" in last("bench_pmc_INSTS.json") else None
+    cells = (bi.get("per_step") or {}).get("poa_cells") or bi.get("poa_cells_per_step")  # (the band cells of the step the counters saw)
     old = json.load(open(os.path.join(dst, "instr.json")))
     cells = cells or old["cells_per_step"]
     ij = {"kernel": kname, "valu_wave_instr_per_64_cells": round(tot["SQ_INSTS_VALU"] * 64 / cells, 1),
