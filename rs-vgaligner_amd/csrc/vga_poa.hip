@@ -1071,7 +1071,10 @@ int poa_run(vga_ctx *ctx, poa_feed &feed, const vga_poa_params *params, std::vec
                 }
                 // narrow bands (one step of a 128-thread workgroup covers a typical row): the per-row set-up and the
                 // barriers dominate, and they are per wave -- config 5 (mean width 340): +6 % with 128 threads
-                if (mean_w <= 800.0) nt = 128;  // (the estimate is of a problem's widest rows: about twice its mean band)
+                {
+                    static const double nt128_w = getenv("VGA_POA_NT128_W") ? atof(getenv("VGA_POA_NT128_W")) : 800.0;  // (experiments)
+                    if (mean_w <= nt128_w) nt = 128;  // (the estimate is of a problem's widest rows: about twice its mean band)
+                }
                 if (giant) nt = getenv("VGA_POA_GIANT_NT") ? atoi(getenv("VGA_POA_GIANT_NT")) : 1024;  // (config 4: +5 % over 512, same-box)
                 const char *ent = getenv("VGA_POA_NT");
                 if (ent) nt = atoi(ent);
