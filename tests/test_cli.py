@@ -224,3 +224,20 @@ def test_bench_four_ranks_under_torch_distributed_on_one_gpu():
     assert j["n_gpus"] == 4 and j["scaling"] == "weak" and j["steps"] == 1
     assert j["whole_job"]["reads"] == 800 and j["whole_job"]["ranks"] == 4 and 790 <= j["whole_job"]["aligned"] <= 800
     assert abs(j["value"] - j["whole_job"]["aligned"] / (j["ms_per_step"] * 1e-3)) <= 0.01 * j["value"]
+
+
+@pytest.mark.gpu
+def test_cli_config5_streams_several_chunks_of_the_1_mbp_pangenome(tmp_path):
+    """BASELINE config 5 through the product CLI at a size that takes several chunks (60 000 reads x 10 kbp on the 1 Mbp synthetic
+    pangenome: 4.9 GB of GAF; tests/prof_million_reads.py is the same harness at the full 1 000 000 reads -- 25 s, 81 GB): one
+    alignment record per read in read order, every read aligned, and the records of the first 2 000 reads byte-identical to a run of
+    those reads alone (src/map.rs:56-111,162-167,219-226)."""
+    pkg()
+    import prof_million_reads as pm
+    d = str(tmp_path)
+    res = pm.run(60000, os.path.join(d, "out"), os.path.join(d, "work"), parts=8, quiet=True)
+    print(res)
+    assert res["alignment_records"] == 60000 and res["aligned"] == 60000
+    assert res["first_2000_records_identical_to_a_run_of_their_own"]
+    assert any("batch(es)" in ln and " 1 batch" not in ln for ln in res["stderr_tail"]), res["stderr_tail"]
+
