@@ -48,6 +48,7 @@ t = {"kernel": "poa_band_dp", "reads": 10000, "read_len": 10000, "fetch_size_kib
      "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace --kernel-include-regex k_poa_dp -- python3 bench.py "
                f"--steps 1 --warmup 0 --cpu-sample 0 (tests/collect_profiles.sh {tag}; raw rows in profiles/{rnd}_{tag}_pmc_poa_dp.txt)",
      "launches_in_pmc_step": launches, "hbm_bytes_per_step": hbm, "algorithmic_bytes_per_step": alg, "ratio": hbm / alg,
+     "remain_rule": 1 if (b.get("config") or {}).get("poa_remain_rule") == "first-out-edge" else 0, "tag": tag,
      "note": "bench.py divides hbm_bytes_per_step by its own launches per step; the traceback is fused into the DP kernel, so its reads of the direction bytes are included"}
 json.dump(t, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 b, br = last("bench.json"), last("bench_under_rocprof.json")
@@ -80,6 +81,7 @@ if os.path.exists(ip):
           "lds_wave_instr_per_64_cells": round(tot["SQ_INSTS_LDS"] * 64 / cells, 1), "cells_per_step": cells,
           "sq_insts_valu_per_step": tot["SQ_INSTS_VALU"], "sq_insts_salu_per_step": tot["SQ_INSTS_SALU"],
           "peak_Gwaveinst_per_s": old["peak_Gwaveinst_per_s"],
+          "remain_rule": 1 if (bi.get("config") or {}).get("poa_remain_rule") == "first-out-edge" else 0,
           "source": f"rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU ... --kernel-trace --kernel-include-regex k_poa_dp -- python3 bench.py --steps 1 --warmup 0 "
                     f"--cpu-sample 0 (tests/collect_profiles.sh {tag}; raw rows in profiles/{rnd}_{tag}_pmc_insts.txt); peak: tests/microbench/valu_issue.hip, "
                     "profiles/r02_valu_issue_microbench.txt (v_max_i32 / VOP3 / DPP / SDWA / v_pk_* at 6 waves per SIMD: 0.53-0.60 T/s)"}
